@@ -1,0 +1,315 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the REFERENCE's own `models/` package (imported from
+/root/reference, never copied) on seeded inputs and dumps inputs + outputs + intermediates
+as small .npz fixtures next to this script.
+
+Run in the build container only:   python tests/golden/gen_golden.py
+/root/reference does not exist on the GPU box; nothing at test time imports it.  Fixtures hold
+tensors and JSON config only (no pickled classes).
+
+`utils.get_free_mask` lives in a module that imports cv2/torchvision/plyfile/skimage (absent
+here, and irrelevant to the mask arithmetic); those four names are gated with empty stub
+modules for the duration of that one import.
+"""
+import io
+import json
+import os
+import sys
+import types
+import contextlib
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+
+with contextlib.redirect_stdout(io.StringIO()):
+    from models.tensoRF import TensorVMSplit, TensorCP          # noqa: E402
+    from models.tensorBase import AlphaGridMask, raw2alpha      # noqa: E402
+    from models import mlp as ref_mlp                           # noqa: E402
+    from models.sh import eval_sh_bases                         # noqa: E402
+
+torch.set_default_dtype(torch.float32)
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def base_args(**over):
+    a = dict(step_ratio=0.5, fea2denseAct="softplus", density_n_comp=[16, 16, 16], app_n_comp=[48, 48, 48],
+             app_dim=27, density_shift=-10.0, distance_scale=25.0, alphaMask_thres=0.001,
+             shadingMode="MLP_Fea", pos_pe=2, view_pe=2, fea_pe=2, featureC=128)
+    a.update(over)
+    return a
+
+
+def ball_volume(res, aabb, radius):
+    lin = [torch.linspace(float(aabb[0][k]), float(aabb[1][k]), res[k]) for k in range(3)]
+    zz, yy, xx = torch.meshgrid(lin[2], lin[1], lin[0], indexing="ij")
+    return ((xx ** 2 + yy ** 2 + zz ** 2) < radius ** 2).float()     # (Gz,Gy,Gx)
+
+
+def outside_rays(n, seed, radius=4.0, spread=1.0):
+    g = torch.Generator().manual_seed(seed)
+    o = torch.randn(n, 3, generator=g)
+    o = o / o.norm(dim=-1, keepdim=True) * radius
+    tgt = (torch.rand(n, 3, generator=g) * 2 - 1) * spread
+    d = tgt - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    return torch.cat([o, d], 1)
+
+
+def pack(mask):
+    return np.packbits(mask.cpu().numpy().astype(np.uint8).reshape(-1))
+
+
+def run_case(name, model, rays, *, mask=None, white_bg=True, is_train=False, ndc_ray=False, N_samples=-1,
+             seed=1234, with_grad=False, model_name="TensorVMSplit", extra_cfg=None, store_state=True):
+    """Calls the reference's methods for intermediates, then its forward for the outputs."""
+    out = {}
+    # ---- intermediates via the reference's own methods (mirrors the call order of forward)
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        if ndc_ray:
+            pts, z, valid = model.sample_ray_ndc(rays[:, :3], rays[:, 3:6], is_train=is_train, N_samples=N_samples)
+            dists = torch.cat((z[:, 1:] - z[:, :-1], torch.zeros_like(z[:, :1])), dim=-1)
+            dists = dists * torch.norm(rays[:, 3:6], dim=-1, keepdim=True)
+            z_full = z.expand(rays.shape[0], -1)
+        else:
+            pts, z, valid = model.sample_ray(rays[:, :3], rays[:, 3:6], is_train=is_train, N_samples=N_samples)
+            dists = torch.cat((z[:, 1:] - z[:, :-1], torch.zeros_like(z[:, :1])), dim=-1)
+            z_full = z
+        out["mid/z"] = z_full.numpy().copy()
+        out["mid/bbox_valid"] = pack(valid)
+        valid2 = valid.clone()
+        if model.alphaMask is not None:
+            a = model.alphaMask.sample_alpha(pts[valid])
+            valid2[valid] = a > 0
+        out["mid/ray_valid"] = pack(valid2)
+        den_mask = None if mask is None else mask["decomp"]["den"]
+        app_mask_d = None if mask is None else mask["decomp"]["app"]
+        enc_mask = {"pos": None, "view": None, "fea": None} if mask is None else mask["encoding"]
+        sigma = torch.zeros(pts.shape[:-1])
+        xyz_n = model.normalize_coord(pts)
+        if valid2.any():
+            f = model.compute_densityfeature(xyz_n[valid2], den_mask)
+            sigma[valid2] = model.feature2density(f)
+        _, weight, _ = raw2alpha(sigma, dists * model.distance_scale)
+        app = weight > model.rayMarch_weight_thres
+        out["mid/sigma"] = sigma.numpy()
+        out["mid/weight"] = weight.numpy()
+        out["mid/app_mask"] = pack(app)
+        out["mid/app_margin"] = np.float32((weight - model.rayMarch_weight_thres).abs().min().item())
+        if app.any():
+            feats = model.compute_appfeature(xyz_n[app], app_mask_d)
+            out["mid/app_features"] = feats.numpy()
+            vd = rays[:, 3:6]
+            if ndc_ray:
+                vd = vd / torch.norm(vd, dim=-1, keepdim=True)
+            vd = vd.view(-1, 1, 3).expand(pts.shape)
+            out["mid/rgb_samples"] = model.renderModule(xyz_n[app], vd[app], feats, mask=enc_mask).numpy()
+        out["mid/shape"] = np.array(list(pts.shape[:2]), dtype=np.int64)
+
+    # ---- the real thing
+    torch.manual_seed(seed)
+    if with_grad:
+        model.zero_grad()
+        rgb, depth, nvalid = model(rays, mask, white_bg=white_bg, is_train=is_train, ndc_ray=ndc_ray, N_samples=N_samples)
+        g = torch.Generator().manual_seed(seed + 1)
+        target = torch.rand(rays.shape[0], 3, generator=g)
+        loss = torch.mean((rgb - target) ** 2)
+        loss.backward()
+        out["grad/target"] = target.numpy()
+        out["grad/loss"] = np.float32(loss.item())
+        for k, p in model.named_parameters():
+            out["grad/" + k] = (torch.zeros_like(p) if p.grad is None else p.grad).numpy()
+    else:
+        with torch.no_grad():
+            rgb, depth, nvalid = model(rays, mask, white_bg=white_bg, is_train=is_train, ndc_ray=ndc_ray, N_samples=N_samples)
+    out["out/rgb_map"] = rgb.detach().numpy()
+    out["out/depth_map"] = depth.detach().numpy()
+    out["out/num_valid_samples"] = np.int64(nvalid.item())
+
+    cfg = dict(model=model_name, aabb=model.aabb.tolist(), gridSize=model.gridSize.tolist(),
+               near_far=[float(v) for v in model.near_far], step_ratio=model.step_ratio,
+               fea2denseAct=model.fea2denseAct, density_n_comp=list(model.density_n_comp),
+               app_n_comp=list(model.app_n_comp), app_dim=model.app_dim, density_shift=model.density_shift,
+               distance_scale=model.distance_scale, shadingMode=model.shadingMode, pos_pe=model.pos_pe,
+               view_pe=model.view_pe, fea_pe=model.fea_pe, featureC=model.featureC,
+               rayMarch_weight_thres=model.rayMarch_weight_thres, alphaMask_thres=model.alphaMask_thres,
+               stepSize=float(model.stepSize), nSamples=int(model.nSamples),
+               call=dict(white_bg=white_bg, is_train=is_train, ndc_ray=ndc_ray, N_samples=N_samples, seed=seed))
+    if extra_cfg:
+        cfg.update(extra_cfg)
+    out["cfg_json"] = np.array(json.dumps(cfg))
+    out["rays"] = rays.numpy()
+    if store_state:
+        for k, v in model.state_dict().items():
+            if k.startswith("alphaMask"):
+                continue
+            out["state/" + k] = v.numpy()
+    if model.alphaMask is not None:
+        out["alpha_volume"] = model.alphaMask.alpha_volume[0, 0].numpy().astype(np.uint8)
+        out["alpha_aabb"] = model.alphaMask.aabb.numpy()
+    if mask is not None:
+        for grp in ("encoding", "decomp"):
+            for k, v in mask[grp].items():
+                if v is None:
+                    continue
+                if isinstance(v, (list, tuple)):
+                    for i, vi in enumerate(v):
+                        out[f"mask/{grp}/{k}/{i}"] = vi.numpy()
+                else:
+                    out[f"mask/{grp}/{k}"] = v.numpy()
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: rays {tuple(rays.shape)} N={int(out['mid/shape'][1])} bbox_valid={int(valid.sum())} "
+          f"ray_valid={int(valid2.sum())} shaded={int(out['out/num_valid_samples'])} "
+          f"margin={float(out['mid/app_margin']):.2e}  -> {os.path.getsize(path)/1e6:.2f} MB")
+
+
+def trained_like_vm(model, ball_res=None, radius=0.8, den_boost=(10.0, 1.0)):
+    with torch.no_grad():
+        model.density_plane[0][:, 0] = den_boost[0]
+        model.density_line[0][:, 0] = den_boost[1]
+    if ball_res is not None:
+        model.alphaMask = AlphaGridMask("cpu", model.aabb, ball_volume(ball_res, model.aabb, radius))
+    return model
+
+
+def main():
+    cube = torch.tensor([[-1.5, -1.5, -1.5], [1.5, 1.5, 1.5]])
+
+    # 1/2: VMSplit cubic, production component counts, MLP_Fea, alpha mask; eval + train(+grads)
+    torch.manual_seed(0)
+    m = quiet(TensorVMSplit, base_args(), cube, [40, 40, 40], [2.0, 6.0], "cpu")
+    trained_like_vm(m, ball_res=(32, 32, 32))
+    run_case("vm_cubic_eval", m, outside_rays(192, 11))
+    run_case("vm_cubic_train", m, outside_rays(128, 12), is_train=True, seed=77, with_grad=True, store_state=False,
+             extra_cfg=dict(state_from="vm_cubic_eval"))
+    # explicit N_samples override + no white bg in eval
+    run_case("vm_cubic_eval_nobg_n96", m, outside_rays(96, 13), white_bg=False, N_samples=96, store_state=False,
+             extra_cfg=dict(state_from="vm_cubic_eval"))
+    # train without white_bg -> consumes the random-background draw after the jitter draw
+    run_case("vm_cubic_train_randbg", m, outside_rays(64, 14), white_bg=False, is_train=True, seed=5,
+             store_state=False, extra_cfg=dict(state_from="vm_cubic_eval"))
+    run_case("vm_cubic_train_randbg2", m, outside_rays(64, 14), white_bg=False, is_train=True, seed=10,
+             store_state=False, extra_cfg=dict(state_from="vm_cubic_eval"))
+
+    # masks: scalar encoding masks + per-plane-indexable decomposition masks (types as utils.get_free_mask
+    # produces them: 0-dim tensors and one 1-D vector indexed by plane id), with non-trivial values
+    mask_a = {"encoding": {"pos": None, "view": torch.tensor(0.625), "fea": torch.tensor(0.3125)},
+              "decomp": {"den": torch.tensor([1.0, 0.75, 0.5] + [0.0] * 13), "app": torch.linspace(1.0, 0.1, 48)}}
+    run_case("vm_cubic_mask_scalar", m, outside_rays(96, 15), mask=mask_a, is_train=True, seed=3, with_grad=True,
+             store_state=False, extra_cfg=dict(state_from="vm_cubic_eval"))
+    # list-of-vectors decomposition masks (C_i,) and vector encoding masks
+    g = torch.Generator().manual_seed(4)
+    mask_b = {"encoding": {"pos": None, "view": torch.rand(12, generator=g), "fea": torch.rand(108, generator=g)},
+              "decomp": {"den": [torch.rand(16, generator=g) for _ in range(3)],
+                         "app": [torch.rand(48, generator=g) for _ in range(3)]}}
+    run_case("vm_cubic_mask_vector", m, outside_rays(96, 16), mask=mask_b, store_state=False,
+             extra_cfg=dict(state_from="vm_cubic_eval"))
+
+    # 3: non-cubic grid, unequal comps, relu density, no PE, no alpha mask
+    torch.manual_seed(1)
+    box = torch.tensor([[-1.2, -1.6, -0.9], [1.4, 1.3, 1.1]])
+    m3 = quiet(TensorVMSplit, base_args(density_n_comp=[16, 4, 4], app_n_comp=[48, 12, 12], fea2denseAct="relu",
+                                        view_pe=0, fea_pe=0, featureC=64), box, [36, 44, 28], [2.0, 6.0], "cpu")
+    with torch.no_grad():
+        m3.density_plane[0][:, 0] = 0.35
+        m3.density_line[0][:, 0] = 0.35
+    run_case("vm_noncubic_relu", m3, outside_rays(128, 21, spread=0.8), is_train=True, seed=9, with_grad=True)
+
+    # 4: NDC forward-facing (llff bbox, near_far [0,1]), eval + train (shared (1,N) jitter)
+    torch.manual_seed(2)
+    ndc_box = torch.tensor([[-1.5, -1.67, -1.0], [1.5, 1.67, 1.0]])
+    m4 = quiet(TensorVMSplit, base_args(density_n_comp=[16, 4, 4], app_n_comp=[48, 12, 12]), ndc_box,
+               [30, 34, 20], [0.0, 1.0], "cpu")
+    with torch.no_grad():
+        m4.density_plane[0][:, 0] = 3.3
+        m4.density_line[0][:, 0] = 3.3
+    g = torch.Generator().manual_seed(31)
+    o = torch.cat([(torch.rand(128, 2, generator=g) * 2 - 1) * torch.tensor([1.2, 1.3]), -torch.ones(128, 1)], 1)
+    d = torch.cat([(torch.rand(128, 2, generator=g) * 2 - 1) * 0.3, 2.0 * torch.ones(128, 1)], 1)
+    ndc_rays = torch.cat([o, d], 1)
+    run_case("vm_ndc_eval", m4, ndc_rays, ndc_ray=True, white_bg=False, N_samples=80)
+    run_case("vm_ndc_train", m4, ndc_rays, ndc_ray=True, white_bg=False, is_train=True, N_samples=80, seed=41,
+             with_grad=True, store_state=False, extra_cfg=dict(state_from="vm_ndc_eval"))
+
+    # 5: Tanks&Temples-like: near 0.01, origins inside the box, exact-zero direction components
+    torch.manual_seed(3)
+    m5 = quiet(TensorVMSplit, base_args(density_n_comp=[8, 8, 8], app_n_comp=[24, 24, 24]), cube, [32, 32, 32],
+               [0.01, 6.0], "cpu")
+    trained_like_vm(m5, ball_res=(24, 28, 20), radius=1.0, den_boost=(3.5, 3.0))
+    g = torch.Generator().manual_seed(51)
+    o = (torch.rand(160, 3, generator=g) * 2 - 1) * 1.2
+    d = torch.randn(160, 3, generator=g)
+    d[:40, 0] = 0.0
+    d[40:60, 1] = 0.0
+    d[60:70, :2] = 0.0
+    d = d / d.norm(dim=-1, keepdim=True)
+    run_case("vm_tnt_inside", m5, torch.cat([o, d], 1))
+
+    # 6: TensorCP (positional construction as the reference's signature forces, then near_far fixed up)
+    torch.manual_seed(4)
+    mc = quiet(TensorCP, base_args(density_n_comp=[32], app_n_comp=[96]), cube, [48, 48, 48], "cpu")
+    mc.near_far = [2.0, 6.0]
+    with torch.no_grad():
+        for i in range(3):
+            mc.density_line[i][:, 0] = 2.2
+    mc.alphaMask = AlphaGridMask("cpu", mc.aabb, ball_volume((32, 32, 32), mc.aabb, 0.9))
+    run_case("cp_eval", mc, outside_rays(128, 61), model_name="TensorCP")
+    mask_c = {"encoding": {"pos": None, "view": torch.tensor(0.5), "fea": None},
+              "decomp": {"den": torch.linspace(1, 0.2, 32)[None], "app": torch.linspace(0.3, 1, 96)[None]}}
+    run_case("cp_train_mask", mc, outside_rays(96, 62), mask=mask_c, is_train=True, seed=8, with_grad=True,
+             model_name="TensorCP", store_state=False, extra_cfg=dict(state_from="cp_eval"))
+
+    # 7: the other two MLP heads
+    for mode in ("MLP", "MLP_PE"):
+        torch.manual_seed(5)
+        mh = quiet(TensorVMSplit, base_args(shadingMode=mode, density_n_comp=[8, 8, 8], app_n_comp=[16, 16, 16],
+                                            featureC=64), cube, [32, 32, 32], [2.0, 6.0], "cpu")
+        trained_like_vm(mh, ball_res=(24, 24, 24))
+        mk = {"encoding": {"pos": torch.tensor(0.4), "view": torch.tensor(0.7), "fea": torch.tensor(0.9)},
+              "decomp": {"den": None, "app": None}}
+        run_case(f"vm_head_{mode}", mh, outside_rays(96, 71), mask=mk, is_train=True, seed=2, with_grad=True)
+
+    # 8: SH / RGB heads called directly (unreachable through TensorBase in the reference, SURVEY warning 4)
+    g = torch.Generator().manual_seed(81)
+    feats = torch.randn(300, 27, generator=g) * 0.5
+    dirs = torch.randn(300, 3, generator=g)
+    dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+    np.savez_compressed(os.path.join(OUT, "sh_head.npz"), feats=feats.numpy(), dirs=dirs.numpy(),
+                        rgb_sh=ref_mlp.SHRender(None, dirs, feats).numpy(),
+                        rgb_passthrough=ref_mlp.RGBRender(None, dirs, feats[:, :3]).numpy(),
+                        bases=eval_sh_bases(2, dirs).numpy())
+    print("sh_head done")
+
+    # 9: utils.get_free_mask / N_to_reso / cal_n_samples (pure torch/numpy functions in a module that
+    # imports four absent, unrelated packages -> gated with empty stubs for this import only)
+    for name in ("cv2", "torchvision", "torchvision.transforms", "plyfile", "skimage", "skimage.measure"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["cv2"].COLORMAP_JET = 2      # only read as a default-argument value at import time
+    import utils as ref_utils
+    rec = {}
+    for step in (0, 500, 2999, 3000):
+        fm = ref_utils.get_free_mask(pos_bl=[12], view_bl=[12], fea_bl=[108], den_bl=[16, 16, 16], app_bl=[48, 48, 48],
+                                     step=step, total_step=3000, ratio=1, using_decomp_mask=True)
+        for grp in fm:
+            for k, v in fm[grp].items():
+                rec[f"{step}/{grp}/{k}"] = np.asarray(v.numpy() if torch.is_tensor(v) else [x.numpy() for x in v])
+    rec["n_to_reso_128"] = np.array(ref_utils.N_to_reso(2097156, cube))
+    rec["n_to_reso_300"] = np.array(ref_utils.N_to_reso(27000000, cube))
+    rec["n_to_reso_llff640"] = np.array(ref_utils.N_to_reso(640 ** 3, ndc_box))
+    rec["cal_n_samples_128"] = np.int64(ref_utils.cal_n_samples([128, 128, 128], 0.5))
+    rec["cal_n_samples_300"] = np.int64(ref_utils.cal_n_samples([300, 300, 300], 0.5))
+    np.savez_compressed(os.path.join(OUT, "free_mask.npz"), **rec)
+    print("free_mask done", {k: rec[k].shape for k in rec if k.startswith("0/")})
+
+
+if __name__ == "__main__":
+    main()
