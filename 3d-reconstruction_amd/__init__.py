@@ -1,0 +1,10 @@
+"""MI355X-native TensoRF ray-marching hot path (import as `recon_amd`, see /recon_amd.py)."""
+from . import _hip
+from .field import (AlphaGridMask, MLPRender, MLPRender_Fea, MLPRender_PE, TensorBase, TensorCP, TensorVMSplit,
+                    channel_last_param, is_channel_last)
+from .renderer import OctreeRender_trilinear_fast
+from .utils import N_to_reso, cal_n_samples, get_free_mask
+
+__all__ = ["AlphaGridMask", "MLPRender", "MLPRender_Fea", "MLPRender_PE", "TensorBase", "TensorCP",
+           "TensorVMSplit", "OctreeRender_trilinear_fast", "N_to_reso", "cal_n_samples", "get_free_mask",
+           "channel_last_param", "is_channel_last", "_hip"]

@@ -1,0 +1,119 @@
+"""ctypes binding of libtensorf_hip.so (C ABI declared in include/tensorf_hip.h).
+
+The library is the product: there is no CPU or eager fallback.  `lib()` raises when the shared object is
+missing, and every entry point raises `HipError` on a non-zero hipError_t.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtensorf_hip.so")
+
+N_SHARDS = 64
+SHARD_STRIDE = 32
+MAX_SAMPLES = 8192
+TILE = 64
+
+MODEL_VM, MODEL_CP = 0, 1
+ACT_SOFTPLUS, ACT_RELU = 0, 1
+HEAD_MLP, HEAD_SH, HEAD_RGB = 0, 1, 2
+SRC_FEAT, SRC_VIEW, SRC_PTS = 0, 1, 2
+
+_fp = C.c_void_p
+
+
+class TfFactors(C.Structure):
+    _fields_ = [("plane", _fp * 3), ("line", _fp * 3), ("mask", _fp * 3), ("n_comp", C.c_int * 3)]
+
+
+class TfFactorGrads(C.Structure):
+    _fields_ = [("plane", _fp * 3), ("line", _fp * 3)]
+
+
+class TfField(C.Structure):
+    _fields_ = [("model", C.c_int), ("act", C.c_int), ("grid", C.c_int * 3),
+                ("aabb_lo", C.c_float * 3), ("aabb_hi", C.c_float * 3), ("inv_aabb", C.c_float * 3),
+                ("near_", C.c_float), ("far_", C.c_float), ("step", C.c_float),
+                ("distance_scale", C.c_float), ("density_shift", C.c_float), ("weight_thres", C.c_float),
+                ("density", TfFactors),
+                ("alpha_cells", _fp), ("alpha_grid", C.c_int * 3), ("alpha_lo", C.c_float * 3),
+                ("alpha_inv", C.c_float * 3)]
+
+
+class TfMarchIO(C.Structure):
+    _fields_ = [("rays", _fp), ("n_rays", C.c_int), ("n_samples", C.c_int), ("ndc", C.c_int),
+                ("jitter", _fp), ("z_table", _fp), ("save_valid", C.c_int), ("t_stop", C.c_float),
+                ("acc", _fp), ("depth", _fp), ("app_offset", _fp), ("app_count", _fp), ("val_count", _fp),
+                ("counters", _fp), ("app_ray", _fp), ("app_xyz", _fp), ("app_w", _fp),
+                ("val_idx", _fp), ("val_feat", _fp), ("dbg_bbox_bits", _fp), ("dbg_valid_bits", _fp),
+                ("dbg_app_bits", _fp)]
+
+
+class TfPeBlock(C.Structure):
+    _fields_ = [("src", C.c_int), ("freqs", C.c_int), ("mask", _fp)]
+
+
+class TfShade(C.Structure):
+    _fields_ = [("model", C.c_int), ("grid", C.c_int * 3), ("app", TfFactors), ("app_dim", C.c_int),
+                ("n_app_total", C.c_int), ("head", C.c_int), ("basis", _fp), ("n_pe", C.c_int),
+                ("pe", TfPeBlock * 3), ("in_c", C.c_int), ("feature_c", C.c_int),
+                ("w1", _fp), ("b1", _fp), ("w2", _fp), ("b2", _fp), ("w3", _fp), ("b3", _fp)]
+
+
+class TfShadeGrads(C.Structure):
+    _fields_ = [("w1", _fp), ("b1", _fp), ("w2", _fp), ("b2", _fp), ("w3", _fp), ("b3", _fp),
+                ("basis", _fp), ("app", TfFactorGrads)]
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_SIGS = {
+    "tf_pack_alpha_cells": [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp],
+    "tf_pack_matrix": [_fp, C.c_int, C.c_int, _fp, C.c_int, _fp],
+    "tf_march_forward": [C.POINTER(TfField), C.POINTER(TfMarchIO), _fp],
+    "tf_shade_forward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp],
+    "tf_composite_forward": [C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp],
+    "tf_density_points": [C.POINTER(TfField), _fp, C.c_int, _fp, _fp],
+    "tf_appfeature_points": [C.POINTER(TfShade), _fp, C.c_int, _fp, _fp],
+}
+_PENDING = {
+    "tf_march_backward": [C.POINTER(TfField), C.POINTER(TfMarchIO), _fp, _fp, C.c_int, _fp, _fp,
+                          C.POINTER(TfFactorGrads), _fp],
+    "tf_shade_backward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp,
+                          C.POINTER(TfShadeGrads), _fp],
+}
+EXPORTS = tuple(_SIGS) + ("tf_build_info",)
+
+
+def lib():
+    """Loads the HIP library once.  No fallback: a missing build is a hard error."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                           f"g.build()'` (or `make -C 3d-reconstruction_amd/csrc`). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        missing = [n for n in EXPORTS if not hasattr(L, n)]
+        if missing:
+            raise HipError(f"{LIB_PATH} does not export {missing}: stale build, rebuild it")
+        for name, args in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        L.tf_build_info.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def check(err, what):
+    if err != 0:
+        raise HipError(f"{what} failed with hipError_t {err}")
+
+
+def ptr(t):
+    """Device (or host) address of a tensor, None -> NULL."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,306 @@
+// march.hip — ray marching: sampling, bbox/alpha-mask tests, wave-level compaction, VM/CP density
+// lookup, transmittance scan, weight threshold and the per-ray reductions.   gfx950, wave64.
+//
+// One wavefront (= one 64-thread workgroup) owns one ray:
+//   phase A  every lane tests one sample per iteration (position, bbox, 1-byte alpha-cell lookup);
+//            survivors are compacted in order into an LDS queue with ballot + mbcnt.
+//   phase B  the queue is consumed 64 entries at a time; 4 lanes cooperate on one sample so that each
+//            bilinear tap of the channel-last factor tensors is ONE contiguous 64-B segment.
+//   phase C  one lane per queue entry: activation, alpha, wave product-scan of the transmittance,
+//            weights, acc/depth partial sums, `w > thres` ballot -> shaded entries are staged in the
+//            already-consumed part of the LDS queue.
+//   end      one atomic per ray reserves a contiguous range of the packed app list (64 counter shards
+//            on separate cache lines, so the reservation rate never limits the kernel).
+// Replaces tensorBase.py:178-208 (sampling), :349-354 (alpha mask), :360-370 (density, raw2alpha,
+// app_mask), :377,:386-388 (acc/depth) and tensoRF.py:207-227 / :358-386.
+#include "tf_device.h"
+
+using namespace tf;
+
+namespace {
+
+constexpr int kShards = TF_N_SHARDS;
+constexpr int kShardStride = TF_SHARD_STRIDE;
+
+__device__ __forceinline__ Ray load_ray(const TfField& F, const TfMarchIO& io, int r) {
+    Ray ray;
+    const float* rp = io.rays + (size_t)r * 6;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        ray.o[a] = rp[a];
+        ray.d[a] = rp[3 + a];
+    }
+    ray.jit = 0.f;
+    ray.tmin = 0.f;
+    ray.dnorm = 1.f;
+    if (io.ndc) {
+        // torch.norm(viewdirs, dim=-1): sqrt(x*x + y*y + z*z)   (tensorBase.py:341)
+        float s = ray.d[0] * ray.d[0];
+        s = s + ray.d[1] * ray.d[1];
+        s = s + ray.d[2] * ray.d[2];
+        ray.dnorm = sqrtf(s);
+    } else {
+        ray.tmin = slab_tmin(F, ray);
+        if (io.jitter) ray.jit = io.jitter[r];
+    }
+    return ray;
+}
+
+__global__ __launch_bounds__(64) void march_forward_kernel(const TfField F, const TfMarchIO io) {
+    extern __shared__ float smem[];
+    const int N = io.n_samples;
+    const int ncap = (N + 63) & ~63;
+    float* wq = smem;                                  // staged weights of shaded samples
+    float* fbuf = smem + ncap;                         // density features of the current 64 entries
+    uint16_t* q = reinterpret_cast<uint16_t*>(fbuf + 64);  // compacted sample indices
+
+    const int lane = threadIdx.x;
+    const int r = xcd_remap(blockIdx.x, gridDim.x);
+    const int shard = blockIdx.x & (kShards - 1);
+    const Ray ray = load_ray(F, io, r);
+    const float* ztab = io.ndc ? io.z_table : nullptr;
+    const int words = (N + 63) >> 6;
+
+    // ---------------- phase A: validity + compaction
+    int cnt = 0, nbbox = 0;
+    for (int base = 0; base < N; base += 64) {
+        const int i = base + lane;
+        bool inb = false, val = false;
+        if (i < N) {
+            float z = sample_z(F, ray, ztab, i);
+            float p[3];
+            sample_pos(ray, z, p);
+            inb = in_bbox(F, p);
+            val = inb && (F.alpha_cells == nullptr || alpha_hit(F, p));
+        }
+        const uint64_t mb = __ballot(inb), mv = __ballot(val);
+        if (lane == 0) {
+            if (io.dbg_bbox_bits) io.dbg_bbox_bits[(size_t)r * words + (base >> 6)] = mb;
+            if (io.dbg_valid_bits) io.dbg_valid_bits[(size_t)r * words + (base >> 6)] = mv;
+        }
+        if (val) q[cnt + prefix_popc(mv)] = (uint16_t)i;
+        cnt += __popcll(mv);
+        nbbox += __popcll(mb);
+    }
+    __syncthreads();
+
+    // ---------------- phases B + C over the compacted queue
+    float T = 1.f, acc_l = 0.f, dep_l = 0.f;
+    int appcnt = 0, done = 0;
+    const size_t vbase = (size_t)r * N;
+    for (int kb = 0; kb < cnt; kb += 64) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int slot = kb + s * 16 + (lane >> 2);
+            float part = 0.f;
+            if (slot < cnt) {
+                const int idx = q[slot];
+                float p[3], u[3];
+                sample_pos(ray, sample_z(F, ray, ztab, idx), p);
+                normalize(F, p, u);
+                part = density_partial(F.model, F.density, F.grid, u, lane & 3);
+            }
+            const float f = quad_sum(part);
+            if ((lane & 3) == 0) fbuf[s * 16 + (lane >> 2)] = f;
+        }
+        __syncthreads();
+
+        const int slot = kb + lane;
+        const bool act = slot < cnt;
+        const int idx = act ? (int)q[slot] : 0;
+        const float f = fbuf[lane];
+        const float z = sample_z(F, ray, ztab, idx);
+        float alpha = 0.f, t = 1.f;
+        if (act) {
+            const float sigma = density_act(F, f);
+            // dists = z[i+1]-z[i], last sample 0 (tensorBase.py:340,346); NDC scales by |d| (:342)
+            float dist = 0.f;
+            if (idx + 1 < N) dist = sample_z(F, ray, ztab, idx + 1) - z;
+            if (io.ndc) dist = dist * ray.dnorm;
+            const float ds = dist * F.distance_scale;
+            alpha = 1.f - expf(-sigma * ds);                 // tensorBase.py:23
+            t = (1.f - alpha) + 1e-10f;                       // tensorBase.py:25
+        }
+        const float incl = wave_scan_mul(t);
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.f;
+        const float w = alpha * (T * excl);                   // tensorBase.py:27
+        T = T * __shfl(incl, 63, 64);
+        acc_l += w;
+        dep_l += w * z;
+        const bool shade = act && (w > F.weight_thres);       // tensorBase.py:370
+        const uint64_t ms = __ballot(shade);
+        if (shade) {
+            const int j = appcnt + prefix_popc(ms);           // j <= slot: that queue entry is already consumed
+            q[j] = (uint16_t)idx;
+            wq[j] = w;
+            if (io.dbg_app_bits)
+                atomicOr(reinterpret_cast<unsigned*>(io.dbg_app_bits) + (size_t)r * words * 2 + (idx >> 5),
+                         1u << (idx & 31));
+        }
+        appcnt += __popcll(ms);
+        if (io.save_valid && act) {
+            io.val_idx[vbase + slot] = idx;
+            io.val_feat[vbase + slot] = f;
+        }
+        done = min(cnt, kb + 64);
+        __syncthreads();
+        if (T < io.t_stop) break;                             // wave-uniform
+    }
+
+    // ---------------- per-ray results + packed app list
+    const float acc = wave_sum(acc_l);
+    float dep = wave_sum(dep_l);
+    dep = dep + (1.f - acc) * io.rays[(size_t)r * 6 + 5];     // tensorBase.py:388 (last ray column, d_z)
+    int base = 0;
+    if (lane == 0) {
+        int* ctr = io.counters + shard * kShardStride;
+        const int seg_cap = ((gridDim.x + kShards - 1) / kShards) * N;
+        base = shard * seg_cap + (appcnt ? atomicAdd(&ctr[0], appcnt) : 0);
+        atomicAdd(&ctr[1], done);
+        atomicAdd(&ctr[2], nbbox);
+        io.acc[r] = acc;
+        io.depth[r] = dep;
+        io.app_offset[r] = base;
+        io.app_count[r] = appcnt;
+        io.val_count[r] = done;
+    }
+    base = __shfl(base, 0, 64);
+    for (int j = lane; j < appcnt; j += 64) {
+        const int idx = q[j];
+        float p[3], u[3];
+        sample_pos(ray, sample_z(F, ray, ztab, idx), p);
+        normalize(F, p, u);
+        const size_t s = (size_t)base + j;
+        io.app_ray[s] = r;
+        io.app_xyz[s * 3 + 0] = u[0];
+        io.app_xyz[s * 3 + 1] = u[1];
+        io.app_xyz[s * 3 + 2] = u[2];
+        io.app_w[s] = wq[j];
+    }
+}
+
+// compute_densityfeature on an explicit list of normalised points (the public hook used by compute_alpha,
+// tensorBase.py:311): 4 lanes per point, same gather code as the march kernel.
+__global__ __launch_bounds__(256) void density_points_kernel(const TfField F, const float* __restrict__ xyz, int n,
+                                                             float* __restrict__ out) {
+    const int groups = (n + 63) / 64;
+    for (int g = blockIdx.x * 4 + (threadIdx.x >> 6); g < groups; g += gridDim.x * 4) {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int pt = g * 64 + s * 16 + (lane >> 2);
+            float part = 0.f;
+            if (pt < n) {
+                float u[3] = {xyz[(size_t)pt * 3], xyz[(size_t)pt * 3 + 1], xyz[(size_t)pt * 3 + 2]};
+                part = density_partial(F.model, F.density, F.grid, u, lane & 3);
+            }
+            const float f = quad_sum(part);
+            if (pt < n && (lane & 3) == 0) out[pt] = f;
+        }
+    }
+}
+
+// alpha volume (Gz,Gy,Gx) -> one byte per trilinear cell, cell index = floor coordinate + 1.
+__global__ __launch_bounds__(256) void pack_alpha_cells_kernel(const float* __restrict__ vol, int gx, int gy, int gz,
+                                                               uint8_t* __restrict__ cells) {
+    const int sx = gx + 1, sy = gy + 1, sz = gz + 1;
+    const size_t total = (size_t)sx * sy * sz;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (size_t)gridDim.x * blockDim.x) {
+        const int cx = (int)(c % sx), cy = (int)((c / sx) % sy), cz = (int)(c / ((size_t)sx * sy));
+        uint32_t m = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int x = cx - 1 + (b & 1), y = cy - 1 + ((b >> 1) & 1), z = cz - 1 + (b >> 2);
+            if (x >= 0 && x < gx && y >= 0 && y < gy && z >= 0 && z < gz)
+                if (vol[((size_t)z * gy + y) * gx + x] > 0.f) m |= 1u << b;
+        }
+        cells[c] = (uint8_t)m;
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_matrix_kernel(const float* __restrict__ src, int rows, int cols,
+                                                          float* __restrict__ dst, int rows_pad, int kp) {
+    const int total = rows_pad * kp;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int rr = i / kp, c = i % kp;
+        dst[i] = (rr < rows && c < cols) ? src[(size_t)rr * cols + c] : 0.f;
+    }
+}
+
+// rgb_map = sum_k w_k rgb_k (+ 1 - acc) clamped  (tensorBase.py:378-384); a ray's entries are contiguous
+// and in sample order, so the sum order is fixed.
+__global__ __launch_bounds__(256) void composite_kernel(int n_rays, const int* __restrict__ app_offset,
+                                                        const int* __restrict__ app_count,
+                                                        const float* __restrict__ app_w,
+                                                        const float* __restrict__ rgb, const float* __restrict__ acc,
+                                                        int white_bg, float* __restrict__ rgb_map) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const int o = app_offset[r], c = app_count[r];
+    float cr = 0.f, cg = 0.f, cb = 0.f;
+    for (int k = 0; k < c; ++k) {
+        const float w = app_w[o + k];
+        const float* s = rgb + (size_t)(o + k) * 3;
+        cr += w * s[0];
+        cg += w * s[1];
+        cb += w * s[2];
+    }
+    if (white_bg) {
+        const float bg = 1.f - acc[r];
+        cr += bg; cg += bg; cb += bg;
+    }
+    rgb_map[(size_t)r * 3 + 0] = fminf(fmaxf(cr, 0.f), 1.f);
+    rgb_map[(size_t)r * 3 + 1] = fminf(fmaxf(cg, 0.f), 1.f);
+    rgb_map[(size_t)r * 3 + 2] = fminf(fmaxf(cb, 0.f), 1.f);
+}
+
+}  // namespace
+
+extern "C" {
+
+int tf_pack_alpha_cells(const float* volume, int gx, int gy, int gz, uint8_t* cells, tf_stream_t stream) {
+    const size_t total = (size_t)(gx + 1) * (gy + 1) * (gz + 1);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_alpha_cells_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, volume, gx, gy, gz,
+                       cells);
+    return TF_CHECK_LAUNCH();
+}
+
+int tf_pack_matrix(const float* src, int rows, int cols, float* dst, int rows_pad, tf_stream_t stream) {
+    const int kp = (cols + 15) & ~15;
+    const int total = rows_pad * kp;
+    hipLaunchKernelGGL(pack_matrix_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, rows,
+                       cols, dst, rows_pad, kp);
+    return TF_CHECK_LAUNCH();
+}
+
+int tf_march_forward(const TfField* field, const TfMarchIO* io, tf_stream_t stream) {
+    if (io->n_rays <= 0) return 0;
+    if (io->n_samples <= 0 || io->n_samples > TF_MAX_SAMPLES) return (int)hipErrorInvalidValue;
+    const int ncap = (io->n_samples + 63) & ~63;
+    const size_t lds = (size_t)ncap * 6 + 256;
+    hipLaunchKernelGGL(march_forward_kernel, dim3(io->n_rays), dim3(64), lds, (hipStream_t)stream, *field, *io);
+    return TF_CHECK_LAUNCH();
+}
+
+int tf_composite_forward(int n_rays, const int* app_offset, const int* app_count, const float* app_w,
+                         const float* rgb, const float* acc, int white_bg, float* rgb_map, tf_stream_t stream) {
+    if (n_rays <= 0) return 0;
+    hipLaunchKernelGGL(composite_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_rays,
+                       app_offset, app_count, app_w, rgb, acc, white_bg, rgb_map);
+    return TF_CHECK_LAUNCH();
+}
+
+int tf_density_points(const TfField* field, const float* xyz_n, int n, float* out_f, tf_stream_t stream) {
+    if (n <= 0) return 0;
+    int blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(density_points_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *field, xyz_n, n,
+                       out_f);
+    return TF_CHECK_LAUNCH();
+}
+
+const char* tf_build_info(void) { return "tensorf_hip gfx950 wave64 fp32"; }
+
+}  // extern "C"

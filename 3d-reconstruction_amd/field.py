@@ -1,0 +1,642 @@
+"""TensoRF field models on the HIP ray-marching kernels (MI355X / gfx950).
+
+Host-side mirror of the reference's model interface — same class names, constructor arguments,
+attributes, parameter names / shapes and `forward` signature — with the arithmetic of
+`TensorBase.forward` executed by hand-written HIP kernels (csrc/*.hip) through the C ABI in
+include/tensorf_hip.h.  There is no eager / CPU fallback: `forward` raises when the library is
+missing or the tensors are not on a GPU.
+
+Reference interface mirrored here (paths under the reference repo):
+  models/tensorBase.py:30-48   AlphaGridMask
+  models/tensorBase.py:51-395  TensorBase (ctor, update_stepSize, forward, save/load, ...)
+  models/tensoRF.py:141-327    TensorVMSplit
+  models/tensoRF.py:330-484    TensorCP
+  models/mlp.py:27-155         MLPRender_Fea / MLPRender_PE / MLPRender (parameter containers here)
+
+Layout note: factor tensors keep the reference's logical shapes `(1, C, H, W)` / `(1, C, G, 1)` (so
+optimizers, `state_dict` and checkpoints interchange) but are stored channel-LAST in HBM
+(`torch.channels_last`-style strides): one bilinear tap of all C components is one contiguous
+64..192-byte segment, which is what the kernels gather.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _hip as H
+
+MAT_MODE = [[0, 1], [0, 2], [1, 2]]
+VEC_MODE = [2, 1, 0]
+
+
+# ----------------------------------------------------------------------------------------------
+def channel_last_param(values: torch.Tensor) -> nn.Parameter:
+    """(1,C,H,W) values -> Parameter with the same shape whose storage is [H][W][C]."""
+    n, c, h, w = values.shape
+    store = torch.empty((n, h, w, c), dtype=values.dtype, device=values.device)
+    view = store.permute(0, 3, 1, 2)
+    view.copy_(values)
+    return nn.Parameter(view)
+
+
+def is_channel_last(t: torch.Tensor) -> bool:
+    return t.dim() == 4 and t.permute(0, 2, 3, 1).is_contiguous()
+
+
+def channel_last_zeros_like(p: torch.Tensor) -> torch.Tensor:
+    n, c, h, w = p.shape
+    return torch.zeros((n, h, w, c), dtype=p.dtype, device=p.device).permute(0, 3, 1, 2)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f3(t):
+    return (C.c_float * 3)(*[float(v) for v in t])
+
+
+def _i3(t):
+    return (C.c_int * 3)(*[int(v) for v in t])
+
+
+# ----------------------------------------------------------------------------------------------
+class AlphaGridMask(nn.Module):
+    """models/tensorBase.py:30-48.  Keeps the float volume (for save/load parity) and lazily builds the
+    1-byte-per-cell occupancy table the march kernel reads."""
+
+    def __init__(self, device, aabb, alpha_volume):
+        super().__init__()
+        self.device = device
+        self.aabb = aabb.to(self.device)
+        self.aabbSize = self.aabb[1] - self.aabb[0]
+        self.invgridSize = 1.0 / self.aabbSize * 2
+        self.alpha_volume = alpha_volume.view(1, 1, *alpha_volume.shape[-3:])
+        self.gridSize = torch.LongTensor(
+            [alpha_volume.shape[-1], alpha_volume.shape[-2], alpha_volume.shape[-3]]).to(self.device)
+        self._cells = None
+
+    def cells(self):
+        """uint8 [(Gz+1)][(Gy+1)][(Gx+1)] occupancy table (include/tensorf_hip.h)."""
+        if self._cells is None:
+            vol = self.alpha_volume
+            if not vol.is_cuda:
+                raise H.HipError("AlphaGridMask volume must live on the GPU")
+            if float(vol.min()) < 0:
+                raise ValueError("alpha_volume must be non-negative (it is a 0/1 occupancy volume)")
+            vol = vol.contiguous().float()
+            gz, gy, gx = vol.shape[-3:]
+            cells = torch.empty((gz + 1, gy + 1, gx + 1), dtype=torch.uint8, device=vol.device)
+            H.check(H.lib().tf_pack_alpha_cells(vol.data_ptr(), gx, gy, gz, cells.data_ptr(), _stream()),
+                    "tf_pack_alpha_cells")
+            self._cells = cells
+        return self._cells
+
+    def normalize_coord(self, xyz_sampled):
+        return (xyz_sampled - self.aabb[0]) * self.invgridSize - 1
+
+
+# ----------------------------------------------------------------------------------------------
+class _MLPBase(nn.Module):
+    """Parameter container with the reference's layer structure (`mlp.0/2/4`), so `state_dict` keys
+    and `nn.Linear` default initialisation match models/mlp.py:34-38."""
+
+    def _build(self, in_c, featureC):
+        self.in_mlpC = in_c
+        l1, l2, l3 = nn.Linear(in_c, featureC), nn.Linear(featureC, featureC), nn.Linear(featureC, 3)
+        self.mlp = nn.Sequential(l1, nn.ReLU(inplace=True), l2, nn.ReLU(inplace=True), l3)
+        nn.init.constant_(self.mlp[-1].bias, 0)
+
+    def forward(self, pts, viewdirs, features, mask):
+        raise H.HipError("the shading MLP runs fused inside TensorBase.forward (csrc/shade.hip); "
+                         "call the field model, not renderModule, on this build")
+
+
+class MLPRender_Fea(_MLPBase):
+    def __init__(self, inChanel, viewpe=6, feape=6, featureC=128):   # models/mlp.py:27-38
+        super().__init__()
+        self.viewpe, self.feape = viewpe, feape
+        self._build(2 * viewpe * 3 + 2 * feape * inChanel + 3 + inChanel, featureC)
+
+
+class MLPRender_PE(_MLPBase):
+    def __init__(self, inChanel, viewpe=6, pospe=6, featureC=128):   # models/mlp.py:71-82
+        super().__init__()
+        self.viewpe, self.pospe = viewpe, pospe
+        self._build((3 + 2 * viewpe * 3) + (2 * pospe * 3) + inChanel, featureC)
+
+
+class MLPRender(_MLPBase):
+    def __init__(self, inChanel, viewpe=6, pospe=6, feape=6, featureC=128):   # models/mlp.py:109-122
+        super().__init__()
+        self.viewpe, self.pospe, self.feape = viewpe, pospe, feape
+        self._build((2 * pospe * 3) + (2 * viewpe * 3) + (2 * feape * inChanel) + inChanel + 3, featureC)
+
+
+# ----------------------------------------------------------------------------------------------
+class _Workspace:
+    """Scratch for one forward call, carved from a single allocation (sizes follow tensorf_hip.h)."""
+
+    def __init__(self, R, N, device, save_valid, debug):
+        seg_cap = ((R + H.N_SHARDS - 1) // H.N_SHARDS) * N
+        cap = seg_cap * H.N_SHARDS
+        words = (N + 63) // 64
+        spec = [("counters", H.N_SHARDS * H.SHARD_STRIDE, torch.int32), ("acc", R, torch.float32),
+                ("depth", R, torch.float32), ("app_offset", R, torch.int32), ("app_count", R, torch.int32),
+                ("val_count", R, torch.int32), ("rgb_map", R * 3, torch.float32),
+                ("app_ray", cap, torch.int32), ("app_w", cap, torch.float32),
+                ("app_xyz", cap * 3, torch.float32), ("rgb", cap * 3, torch.float32)]
+        if save_valid:
+            spec += [("val_idx", R * N, torch.int32), ("val_feat", R * N, torch.float32),
+                     ("grad_rgb", cap * 3, torch.float32)]
+        if debug:
+            spec += [("dbg_bbox", R * words * 2, torch.int32), ("dbg_valid", R * words * 2, torch.int32),
+                     ("dbg_app", R * words * 2, torch.int32)]
+        total = sum(((n * 4 + 255) // 256) * 256 for _, n, _ in spec)
+        self.buf = torch.empty(total, dtype=torch.uint8, device=device)
+        off = 0
+        for name, n, dt in spec:
+            setattr(self, name, self.buf[off:off + n * 4].view(dt))
+            off += ((n * 4 + 255) // 256) * 256
+        self.R, self.N, self.seg_cap, self.cap, self.words = R, N, seg_cap, cap, words
+        self.save_valid, self.debug = save_valid, debug
+        self.counters2d = self.counters.view(H.N_SHARDS, H.SHARD_STRIDE)
+
+
+class TensorBase(nn.Module):
+    """models/tensorBase.py:51-395 on HIP kernels."""
+
+    def __init__(self, args, aabb, gridSize, near_far=[2.0, 6.0], device='cpu', alphaMask=None,
+                 rayMarch_weight_thres=0.0001):
+        super().__init__()
+        self.aabb = aabb
+        self.device = device
+        self.near_far = near_far
+        self.alphaMask = alphaMask
+        self.rayMarch_weight_thres = rayMarch_weight_thres
+        self.matMode = [list(m) for m in MAT_MODE]
+        self.vecMode = list(VEC_MODE)
+        self.comp_w = [1, 1, 1]
+
+        self.step_ratio = args['step_ratio']
+        self.fea2denseAct = args['fea2denseAct']
+        self.density_n_comp = args['density_n_comp']
+        self.app_n_comp = args['app_n_comp']
+        self.app_dim = args['app_dim']
+        self.density_shift = args['density_shift']
+        self.distance_scale = args['distance_scale']
+        self.alphaMask_thres = args['alphaMask_thres']
+        self.shadingMode = args['shadingMode']
+        self.pos_pe = args['pos_pe']
+        self.view_pe = args['view_pe']
+        self.fea_pe = args['fea_pe']
+        self.featureC = args['featureC']
+
+        self.pos_bit_length = [2 * args['pos_pe'] * 3]
+        self.view_bit_length = [2 * args['view_pe'] * 3]
+        self.fea_bit_length = [2 * args['fea_pe'] * self.app_dim]
+
+        # kernel-side options (not part of the reference interface)
+        self.t_stop = 0.0              # early ray termination threshold on transmittance (0 = off)
+        self._jitter_override = None   # tests: inject the stratified jitter instead of drawing it
+        self._debug_masks = False      # tests: also emit the bbox / valid bitmaps
+        self._ws_cache = {}
+        self._pack_cache = {}
+        self._ztab_cache = {}
+        self.last = None               # workspace of the most recent forward (tests / bench statistics)
+
+        self.init_render_func(self.shadingMode, self.pos_pe, self.view_pe, self.fea_pe, self.featureC, device)
+        self.update_stepSize(gridSize)
+        self.init_svd_volume(gridSize[0], device)
+
+    # ---- construction -------------------------------------------------------------------------
+    def init_render_func(self, shadingMode, pos_pe, view_pe, fea_pe, featureC, device):
+        """models/tensorBase.py:89-98.  'SH' and 'RGB' are accepted as well (the reference defines
+        SHRender/RGBRender, models/mlp.py:15-25, but its dispatcher never reaches them)."""
+        if shadingMode == 'MLP_PE':
+            self.renderModule = MLPRender_PE(self.app_dim, view_pe, pos_pe, featureC).to(device)
+        elif shadingMode == 'MLP_Fea':
+            self.renderModule = MLPRender_Fea(self.app_dim, view_pe, fea_pe, featureC).to(device)
+        elif shadingMode == 'MLP':
+            self.renderModule = MLPRender(self.app_dim, view_pe, pos_pe, fea_pe, featureC).to(device)
+        elif shadingMode in ('SH', 'RGB'):
+            self.renderModule = shadingMode
+        else:
+            raise ValueError(f"Unrecognized shading module {shadingMode!r}")
+
+    def update_stepSize(self, gridSize):
+        """models/tensorBase.py:104-116 (same fp32 torch arithmetic -> same stepSize / nSamples)."""
+        self.aabbSize = self.aabb[1] - self.aabb[0]
+        self.invaabbSize = 2.0 / self.aabbSize
+        self.gridSize = torch.LongTensor(list(gridSize)).to(self.device)
+        self.units = self.aabbSize / (self.gridSize - 1)
+        self.stepSize = torch.mean(self.units) * self.step_ratio
+        self.aabbDiag = torch.sqrt(torch.sum(torch.square(self.aabbSize)))
+        self.nSamples = int((self.aabbDiag / self.stepSize).item()) + 1
+        self._geom = None
+
+    def init_svd_volume(self, res, device):
+        pass
+
+    def normalize_coord(self, xyz_sampled):
+        return (xyz_sampled - self.aabb[0]) * self.invaabbSize - 1
+
+    def get_kwargs(self):
+        """models/tensorBase.py:136-158."""
+        return {
+            'aabb': self.aabb, 'gridSize': self.gridSize.tolist(), 'density_n_comp': self.density_n_comp,
+            'appearance_n_comp': self.app_n_comp, 'app_dim': self.app_dim, 'density_shift': self.density_shift,
+            'alphaMask_thres': self.alphaMask_thres, 'distance_scale': self.distance_scale,
+            'rayMarch_weight_thres': self.rayMarch_weight_thres, 'fea2denseAct': self.fea2denseAct,
+            'near_far': self.near_far, 'step_ratio': self.step_ratio, 'shadingMode': self.shadingMode,
+            'pos_pe': self.pos_pe, 'view_pe': self.view_pe, 'fea_pe': self.fea_pe, 'featureC': self.featureC}
+
+    def save(self, path):
+        """models/tensorBase.py:160-168 (same checkpoint keys, bit-packed alpha volume)."""
+        ckpt = {'kwargs': self.get_kwargs(), 'state_dict': self.state_dict()}
+        if self.alphaMask is not None:
+            alpha_volume = self.alphaMask.alpha_volume.bool().cpu().numpy()
+            ckpt.update({'alphaMask.shape': alpha_volume.shape})
+            ckpt.update({'alphaMask.mask': np.packbits(alpha_volume.reshape(-1))})
+            ckpt.update({'alphaMask.aabb': self.alphaMask.aabb.cpu()})
+        torch.save(ckpt, path)
+
+    def load(self, ckpt):
+        """models/tensorBase.py:170-175."""
+        if 'alphaMask.aabb' in ckpt.keys():
+            length = np.prod(ckpt['alphaMask.shape'])
+            alpha_volume = torch.from_numpy(
+                np.unpackbits(ckpt['alphaMask.mask'])[:length].reshape(ckpt['alphaMask.shape']))
+            self.alphaMask = AlphaGridMask(self.device, ckpt['alphaMask.aabb'].to(self.device),
+                                           alpha_volume.float().to(self.device))
+        self.load_state_dict(ckpt['state_dict'])
+
+    # ---- kernel descriptors -------------------------------------------------------------------
+    def _is_cp(self):
+        return False
+
+    def _factor_lists(self, which):
+        raise NotImplementedError
+
+    def _n_app_total(self):
+        return self.app_n_comp[0] if self._is_cp() else sum(self.app_n_comp)
+
+    def _decomp_mask_vectors(self, m, comps, dev):
+        """Decomposition masks as per-plane (C_i,) device vectors.  `m` is None or anything indexable by
+        plane id whose element broadcasts over (C_i, S) after `[..., None]` (models/tensoRF.py:224)."""
+        if m is None:
+            return [None, None, None]
+        out = []
+        for i in range(1 if self._is_cp() else 3):
+            c = comps[0] if self._is_cp() else comps[i]
+            v = torch.as_tensor(m[i], dtype=torch.float32).to(dev)
+            out.append(torch.broadcast_to(v.reshape(-1) if v.dim() else v, (c,)).contiguous())
+        while len(out) < 3:
+            out.append(None)
+        return out
+
+    def _fill_factors(self, fs: H.TfFactors, planes, lines, masks, comps):
+        for i in range(3):
+            if planes is not None:
+                p = planes[i]
+                if not is_channel_last(p):
+                    raise H.HipError("factor plane is not stored channel-last; build parameters with "
+                                     "channel_last_param()")
+                fs.plane[i] = p.data_ptr()
+            else:
+                fs.plane[i] = None
+            l = lines[i]
+            if not is_channel_last(l):
+                raise H.HipError("factor line is not stored channel-last")
+            fs.line[i] = l.data_ptr()
+            fs.mask[i] = H.ptr(masks[i])
+            fs.n_comp[i] = int(comps[0] if self._is_cp() else comps[i])
+
+    def _field_desc(self, den_masks):
+        f = H.TfField()
+        f.model = H.MODEL_CP if self._is_cp() else H.MODEL_VM
+        if self.fea2denseAct == 'softplus':
+            f.act = H.ACT_SOFTPLUS
+        elif self.fea2denseAct == 'relu':
+            f.act = H.ACT_RELU
+        else:
+            raise ValueError(f"fea2denseAct {self.fea2denseAct!r}")
+        if self._geom is None:   # host copies of the fp32 geometry (one sync per geometry change)
+            self._geom = dict(grid=self.gridSize.tolist(), lo=self.aabb[0].tolist(), hi=self.aabb[1].tolist(),
+                              inv=self.invaabbSize.tolist(), step=float(self.stepSize))
+        g = self._geom
+        f.grid = _i3(g['grid'])
+        f.aabb_lo, f.aabb_hi, f.inv_aabb = _f3(g['lo']), _f3(g['hi']), _f3(g['inv'])
+        f.near_, f.far_ = float(self.near_far[0]), float(self.near_far[1])
+        f.step = g['step']
+        f.distance_scale = float(self.distance_scale)
+        f.density_shift = float(self.density_shift)
+        f.weight_thres = float(self.rayMarch_weight_thres)
+        planes, lines = self._factor_lists('density')
+        self._fill_factors(f.density, planes, lines, den_masks, self.density_n_comp)
+        am = self.alphaMask
+        if am is not None:
+            f.alpha_cells = am.cells().data_ptr()
+            if getattr(am, '_host', None) is None:
+                am._host = dict(grid=am.gridSize.tolist(), lo=am.aabb[0].tolist(), inv=am.invgridSize.tolist())
+            f.alpha_grid, f.alpha_lo, f.alpha_inv = _i3(am._host['grid']), _f3(am._host['lo']), _f3(am._host['inv'])
+        else:
+            f.alpha_cells = None
+        return f
+
+    def _packed(self, key, src, rows_pad):
+        """Zero-padded copy [rows_pad][kpad16(cols)] of a weight matrix, refreshed when it changes."""
+        rows, cols = src.shape
+        kp = (cols + 15) // 16 * 16
+        tag = (src.data_ptr(), src._version, rows_pad, kp)
+        hit = self._pack_cache.get(key)
+        if hit is not None and hit[0] == tag:
+            return hit[1]
+        dst = hit[1] if hit is not None and tuple(hit[1].shape) == (rows_pad, kp) else \
+            torch.empty((rows_pad, kp), dtype=torch.float32, device=src.device)
+        s = src.detach().contiguous()
+        H.check(H.lib().tf_pack_matrix(s.data_ptr(), rows, cols, dst.data_ptr(), rows_pad, _stream()),
+                "tf_pack_matrix")
+        self._pack_cache[key] = (tag, dst)
+        return dst
+
+    def _pe_blocks(self, enc_mask, dev):
+        """Order of the encoding blocks per head (models/mlp.py:41-66, 84-103, 126-153)."""
+        em = enc_mask or {'pos': None, 'view': None, 'fea': None}
+        mode = self.shadingMode
+        blocks = []
+        if mode == 'MLP_Fea':
+            order = [('fea', H.SRC_FEAT, self.fea_pe, self.app_dim), ('view', H.SRC_VIEW, self.view_pe, 3)]
+        elif mode == 'MLP_PE':
+            order = [('pos', H.SRC_PTS, self.pos_pe, 3), ('view', H.SRC_VIEW, self.view_pe, 3)]
+        elif mode == 'MLP':
+            order = [('pos', H.SRC_PTS, self.pos_pe, 3), ('view', H.SRC_VIEW, self.view_pe, 3),
+                     ('fea', H.SRC_FEAT, self.fea_pe, self.app_dim)]
+        else:
+            order = []
+        keep = []
+        for name, src, freqs, dim in order:
+            if freqs <= 0:
+                continue
+            m = em.get(name)
+            mv = None
+            if m is not None:
+                mv = torch.broadcast_to(torch.as_tensor(m, dtype=torch.float32).to(dev), (2 * dim * freqs,)).contiguous()
+                keep.append(mv)
+            blocks.append((src, freqs, mv))
+        return blocks, keep
+
+    def _shade_desc(self, app_masks, enc_mask, dev):
+        s = H.TfShade()
+        s.model = H.MODEL_CP if self._is_cp() else H.MODEL_VM
+        s.grid = _i3(self._geom['grid'])
+        planes, lines = self._factor_lists('app')
+        self._fill_factors(s.app, planes, lines, app_masks, self.app_n_comp)
+        s.app_dim = int(self.app_dim)
+        s.n_app_total = int(self._n_app_total())
+        keep = []
+        nb = (self.app_dim + 15) // 16
+        if nb > 4:
+            raise H.HipError("app_dim > 64 is not supported by the shading kernel")
+        basis = self._packed('basis', self.basis_mat.weight, 16 * nb)
+        s.basis = basis.data_ptr()
+        keep.append(basis)
+        if self.shadingMode in ('SH', 'RGB'):
+            s.head = H.HEAD_SH if self.shadingMode == 'SH' else H.HEAD_RGB
+            if self.shadingMode == 'SH' and self.app_dim != 27:
+                raise ValueError("SH shading needs app_dim == 27 (3 x 9 coefficients)")
+            s.n_pe, s.in_c, s.feature_c = 0, 0, 64
+            return s, keep
+        s.head = H.HEAD_MLP
+        if self.featureC not in (64, 128, 256):
+            raise H.HipError(f"featureC={self.featureC}: the fp32-MFMA shading kernel is built for 64, 128, 256")
+        blocks, k2 = self._pe_blocks(enc_mask, dev)
+        keep += k2
+        s.n_pe = len(blocks)
+        for i, (src, freqs, mv) in enumerate(blocks):
+            s.pe[i].src, s.pe[i].freqs, s.pe[i].mask = src, freqs, H.ptr(mv)
+        mlp = self.renderModule.mlp
+        s.in_c = int(self.renderModule.in_mlpC)
+        s.feature_c = int(self.featureC)
+        w1 = self._packed('w1', mlp[0].weight, self.featureC)
+        w2 = self._packed('w2', mlp[2].weight, self.featureC)
+        keep += [w1, w2]
+        s.w1, s.b1 = w1.data_ptr(), mlp[0].bias.data_ptr()
+        s.w2, s.b2 = w2.data_ptr(), mlp[2].bias.data_ptr()
+        s.w3, s.b3 = mlp[4].weight.data_ptr(), mlp[4].bias.data_ptr()
+        return s, keep
+
+    # ---- sampling inputs (host RNG protocol identical to the reference) ----------------------
+    def _sampling_inputs(self, rays, is_train, ndc_ray, N):
+        """Returns (jitter (R,) or None, z_table (N,) or None) on the rays' device.
+        AABB mode: `rng += torch.rand_like(rng[:, [0]])` draws (R,1) from the CPU default generator
+        (models/tensorBase.py:198-201).  NDC mode: `linspace(near, far, N)` built on the CPU, moved, then
+        `rand_like` on the rays' device scaled by (far-near)/N (models/tensorBase.py:181-183)."""
+        R = rays.shape[0]
+        if not ndc_ray:
+            if not is_train:
+                return None, None
+            j = self._jitter_override
+            if j is None:
+                j = torch.rand(R, 1)
+            return j.reshape(-1).to(device=rays.device, dtype=torch.float32).contiguous(), None
+        near, far = float(self.near_far[0]), float(self.near_far[1])
+        key = (near, far, N, str(rays.device))
+        base = self._ztab_cache.get(key)
+        if base is None:
+            base = torch.linspace(near, far, N).unsqueeze(0).to(rays)
+            self._ztab_cache = {key: base}
+        z = base
+        if is_train:
+            j = self._jitter_override
+            if j is None:
+                j = torch.rand_like(base)
+            z = base + j.to(rays).reshape(1, -1) * ((far - near) / N)
+        return None, z.reshape(-1).contiguous()
+
+    def _workspace(self, R, N, dev, save_valid):
+        key = (R, N, str(dev), save_valid, self._debug_masks)
+        ws = self._ws_cache.get(key)
+        if ws is None or save_valid:
+            ws = _Workspace(R, N, dev, save_valid, self._debug_masks)
+            if not save_valid:
+                self._ws_cache = {key: ws}
+        return ws
+
+    # ---- forward -------------------------------------------------------------------------------
+    def _run_forward(self, rays, mask, white_bg, is_train, ndc_ray, N_samples, save_valid):
+        lib = H.lib()
+        if not rays.is_cuda:
+            raise H.HipError("TensorBase.forward needs rays on the GPU (no CPU path in this build)")
+        rays = rays.detach().to(torch.float32).contiguous()
+        dev = rays.device
+        R = rays.shape[0]
+        N = int(N_samples) if N_samples > 0 else int(self.nSamples)
+        if N > H.MAX_SAMPLES:
+            raise H.HipError(f"N_samples={N} exceeds the per-ray LDS queue ({H.MAX_SAMPLES})")
+        if mask is None:
+            enc_mask, den_m, app_m = None, None, None
+        else:
+            enc_mask, den_m, app_m = mask['encoding'], mask['decomp']['den'], mask['decomp']['app']
+        den_masks = self._decomp_mask_vectors(den_m, self.density_n_comp, dev)
+        app_masks = self._decomp_mask_vectors(app_m, self.app_n_comp, dev)
+
+        jitter, ztab = self._sampling_inputs(rays, is_train, ndc_ray, N)
+        # random background draw happens after the sampling draw (models/tensorBase.py:380)
+        use_bg = bool(white_bg or (is_train and bool(torch.rand((1,)) < 0.5)))
+
+        field = self._field_desc(den_masks)
+        shade, keep = self._shade_desc(app_masks, enc_mask, dev)
+        ws = self._workspace(R, N, dev, save_valid)
+        st = _stream()
+        ws.counters.zero_()
+
+        io = H.TfMarchIO()
+        io.rays, io.n_rays, io.n_samples, io.ndc = rays.data_ptr(), R, N, int(bool(ndc_ray))
+        io.jitter, io.z_table = H.ptr(jitter), H.ptr(ztab)
+        io.save_valid, io.t_stop = int(save_valid), float(self.t_stop)
+        io.acc, io.depth = ws.acc.data_ptr(), ws.depth.data_ptr()
+        io.app_offset, io.app_count, io.val_count = ws.app_offset.data_ptr(), ws.app_count.data_ptr(), ws.val_count.data_ptr()
+        io.counters = ws.counters.data_ptr()
+        io.app_ray, io.app_xyz, io.app_w = ws.app_ray.data_ptr(), ws.app_xyz.data_ptr(), ws.app_w.data_ptr()
+        if save_valid:
+            io.val_idx, io.val_feat = ws.val_idx.data_ptr(), ws.val_feat.data_ptr()
+        if ws.debug:
+            ws.dbg_app.zero_()
+            io.dbg_bbox_bits, io.dbg_valid_bits = ws.dbg_bbox.data_ptr(), ws.dbg_valid.data_ptr()
+            io.dbg_app_bits = ws.dbg_app.data_ptr()
+        H.check(lib.tf_march_forward(C.byref(field), C.byref(io), st), "tf_march_forward")
+        H.check(lib.tf_shade_forward(C.byref(shade), rays.data_ptr(), int(bool(ndc_ray)), ws.counters.data_ptr(),
+                                     ws.seg_cap, ws.app_ray.data_ptr(), ws.app_xyz.data_ptr(), ws.rgb.data_ptr(), st),
+                "tf_shade_forward")
+        H.check(lib.tf_composite_forward(R, ws.app_offset.data_ptr(), ws.app_count.data_ptr(), ws.app_w.data_ptr(),
+                                         ws.rgb.data_ptr(), ws.acc.data_ptr(), int(use_bg), ws.rgb_map.data_ptr(), st),
+                "tf_composite_forward")
+        ctx = dict(ws=ws, rays=rays, field=field, shade=shade, io=io, keep=(keep, den_masks, app_masks, jitter, ztab),
+                   use_bg=use_bg, ndc=bool(ndc_ray))
+        self.last = ctx
+        return ctx
+
+    def forward(self, rays_chunk, mask, white_bg=True, is_train=False, ndc_ray=False, N_samples=-1):
+        """models/tensorBase.py:321-395: returns (rgb_map (R,3), depth_map (R,), num_valid_samples)."""
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if needs_grad:
+            from .autograd import render_with_grad
+            return render_with_grad(self, rays_chunk, mask, white_bg, is_train, ndc_ray, N_samples)
+        ctx = self._run_forward(rays_chunk, mask, white_bg, is_train, ndc_ray, N_samples, save_valid=False)
+        ws = ctx['ws']
+        R = ws.R
+        rgb_map = ws.rgb_map.view(R, 3).clone()
+        depth_map = ws.depth.clone()
+        num_valid = ws.counters2d[:, 0].sum()
+        return rgb_map, depth_map, num_valid
+
+    # ---- public feature hooks (used by compute_alpha in the reference) --------------------------
+    def compute_densityfeature(self, xyz_sampled, mask=None):
+        """models/tensoRF.py:207-227 / :358-386 on a point list of normalised coordinates."""
+        dev = xyz_sampled.device
+        field = self._field_desc(self._decomp_mask_vectors(mask, self.density_n_comp, dev))
+        xyz = xyz_sampled.detach().reshape(-1, 3).to(torch.float32).contiguous()
+        out = torch.empty(xyz.shape[0], dtype=torch.float32, device=dev)
+        H.check(H.lib().tf_density_points(C.byref(field), xyz.data_ptr(), xyz.shape[0], out.data_ptr(), _stream()),
+                "tf_density_points")
+        return out
+
+    def compute_appfeature(self, xyz_sampled, mask=None):
+        """models/tensoRF.py:230-263 / :388-415 on a point list of normalised coordinates."""
+        dev = xyz_sampled.device
+        if self._geom is None:
+            self._field_desc([None, None, None])
+        shade, keep = self._shade_desc(self._decomp_mask_vectors(mask, self.app_n_comp, dev), None, dev)
+        xyz = xyz_sampled.detach().reshape(-1, 3).to(torch.float32).contiguous()
+        out = torch.empty((xyz.shape[0], self.app_dim), dtype=torch.float32, device=dev)
+        H.check(H.lib().tf_appfeature_points(C.byref(shade), xyz.data_ptr(), xyz.shape[0], out.data_ptr(), _stream()),
+                "tf_appfeature_points")
+        return out
+
+    def feature2density(self, density_features):
+        """models/tensorBase.py:291-295 (elementwise; used by callers outside the fused path)."""
+        if self.fea2denseAct == "softplus":
+            return torch.nn.functional.softplus(density_features + self.density_shift)
+        elif self.fea2denseAct == "relu":
+            return torch.relu(density_features)
+
+
+# ----------------------------------------------------------------------------------------------
+class TensorVMSplit(TensorBase):
+    """models/tensoRF.py:141-327."""
+
+    def __init__(self, args, aabb, gridSize, near_far, device):
+        super().__init__(args, aabb, gridSize, near_far, device)
+
+    def init_svd_volume(self, res, device):
+        self.density_plane, self.density_line = self.init_one_svd(self.density_n_comp, self.gridSize, 0.1, device)
+        self.app_plane, self.app_line = self.init_one_svd(self.app_n_comp, self.gridSize, 0.1, device)
+        self.basis_mat = nn.Linear(sum(self.app_n_comp), self.app_dim, bias=False).to(device)
+
+    def init_one_svd(self, n_component, gridSize, scale, device):
+        """Same shapes, init scale and CPU-generator draw order as models/tensoRF.py:152-162; storage is
+        channel-last."""
+        plane_coef, line_coef = [], []
+        for i in range(len(self.vecMode)):
+            vec_id = self.vecMode[i]
+            mat_id_0, mat_id_1 = self.matMode[i]
+            plane_coef.append(channel_last_param(
+                scale * torch.randn((1, n_component[i], int(gridSize[mat_id_1]), int(gridSize[mat_id_0])))))
+            line_coef.append(channel_last_param(scale * torch.randn((1, n_component[i], int(gridSize[vec_id]), 1))))
+        return nn.ParameterList(plane_coef).to(device), nn.ParameterList(line_coef).to(device)
+
+    def _factor_lists(self, which):
+        if which == 'density':
+            return self.density_plane, self.density_line
+        return self.app_plane, self.app_line
+
+    def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001):
+        """models/tensoRF.py:166-172."""
+        grad_vars = [{'params': self.density_line, 'lr': lr_init_spatialxyz},
+                     {'params': self.density_plane, 'lr': lr_init_spatialxyz},
+                     {'params': self.app_line, 'lr': lr_init_spatialxyz},
+                     {'params': self.app_plane, 'lr': lr_init_spatialxyz},
+                     {'params': self.basis_mat.parameters(), 'lr': lr_init_network}]
+        if isinstance(self.renderModule, nn.Module):
+            grad_vars += [{'params': self.renderModule.parameters(), 'lr': lr_init_network}]
+        return grad_vars
+
+
+class TensorCP(TensorBase):
+    """models/tensoRF.py:330-484.  The reference's constructor forwards `device` into `near_far`
+    (SURVEY warning 3); keyword `near_far` / `device` are accepted here so train.py's call works."""
+
+    def __init__(self, args, aabb, gridSize, near_far=[2.0, 6.0], device='cpu', **kargs):
+        super().__init__(args, aabb, gridSize, near_far, device, **kargs)
+
+    def _is_cp(self):
+        return True
+
+    def init_svd_volume(self, res, device):
+        self.density_line = self.init_one_svd(self.density_n_comp[0], self.gridSize, 0.2, device)
+        self.app_line = self.init_one_svd(self.app_n_comp[0], self.gridSize, 0.2, device)
+        self.basis_mat = nn.Linear(self.app_n_comp[0], self.app_dim, bias=False).to(device)
+
+    def init_one_svd(self, n_component, gridSize, scale, device):
+        line_coef = []
+        for i in range(len(self.vecMode)):
+            vec_id = self.vecMode[i]
+            line_coef.append(channel_last_param(scale * torch.randn((1, n_component, int(gridSize[vec_id]), 1))))
+        return nn.ParameterList(line_coef).to(device)
+
+    def _factor_lists(self, which):
+        return None, (self.density_line if which == 'density' else self.app_line)
+
+    def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001):
+        """models/tensoRF.py:350-356."""
+        grad_vars = [{'params': self.density_line, 'lr': lr_init_spatialxyz},
+                     {'params': self.app_line, 'lr': lr_init_spatialxyz},
+                     {'params': self.basis_mat.parameters(), 'lr': lr_init_network}]
+        if isinstance(self.renderModule, nn.Module):
+            grad_vars += [{'params': self.renderModule.parameters(), 'lr': lr_init_network}]
+        return grad_vars

@@ -1,0 +1,192 @@
+/* tensorf_hip.h — C ABI of libtensorf_hip.so (MI355X / gfx950).
+ *
+ * The reference (hautran7201/3D-reconstruction) has no FFI layer: its hot path is Python calling
+ * ATen eager ops.  This header is the drop-in boundary a HIP replacement exports:
+ * plain pointers + sizes, no torch types, no allocation inside, every entry point enqueues on the
+ * caller's stream and returns a hipError_t as int.  Each entry cites the reference code it replaces
+ * (paths relative to the reference repo).
+ *
+ * Memory layout (HBM), all fp32 unless noted:
+ *   rays            (R,6) row-major [ox oy oz dx dy dz]                       renderer.py:18
+ *   plane i         [H=G[mat1]][W=G[mat0]][C_i]  channel-LAST view of the reference's
+ *                   (1,C_i,H,W) parameter (torch channels_last strides, zero copy)  tensoRF.py:157-158
+ *   line i          [G[vec]][C_i]                channel-last view of (1,C_i,G,1)   tensoRF.py:159-160
+ *   alpha cells     uint8 [(Gz+1)][(Gy+1)][(Gx+1)], one byte per trilinear cell: bit (dz*4+dy*2+dx) =
+ *                   alpha_volume[z0+dz][y0+dy][x0+dx] > 0, cell index = floor coord + 1 (so -1..G-1)
+ *                   — the exact `grid_sample(...) > 0` predicate of tensorBase.py:41-45,350-351 in 1 byte
+ *   packed app list one entry per shaded sample (weight > rayMarch_weight_thres), a ray's entries
+ *                   contiguous and in sample order: app_ray[s], app_xyz[s][3] (normalised), app_w[s]
+ */
+#ifndef TENSORF_HIP_H
+#define TENSORF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* tf_stream_t; /* hipStream_t */
+
+/* The packed app list is written through TF_N_SHARDS independent reservation counters (one per
+ * 128-B line, TF_SHARD_STRIDE ints apart) so that one atomic per ray never serialises on a single
+ * word.  Shard g owns packed entries [g*seg_cap, g*seg_cap + counters[g*TF_SHARD_STRIDE]) with
+ * seg_cap = ceil(R / TF_N_SHARDS) * N.  counters[g*STRIDE+1] / [+2] accumulate the number of density
+ * samples / in-bbox samples (statistics for the roofline report). */
+#define TF_N_SHARDS 64
+#define TF_SHARD_STRIDE 32
+#define TF_MAX_SAMPLES 8192   /* samples per ray handled by one LDS queue */
+#define TF_TILE 64            /* shaded samples per shading tile */
+
+enum { TF_MODEL_VM = 0, TF_MODEL_CP = 1 };
+enum { TF_ACT_SOFTPLUS = 0, TF_ACT_RELU = 1 };
+enum { TF_HEAD_MLP = 0, TF_HEAD_SH = 1, TF_HEAD_RGB = 2 };
+enum { TF_SRC_FEAT = 0, TF_SRC_VIEW = 1, TF_SRC_PTS = 2 };
+
+/* One decomposition (density or appearance).  TensorVMSplit: 3 planes + 3 lines, component counts
+ * n_comp[i].  TensorCP: plane[] = NULL, 3 lines of n_comp[0] components.  mask[i] is the per-component
+ * FreeNeRF decomposition mask (C_i floats) or NULL.   tensoRF.py:207-263, 358-415 */
+typedef struct TfFactors {
+    const float* plane[3];
+    const float* line[3];
+    const float* mask[3];
+    int n_comp[3];
+} TfFactors;
+
+/* Gradient destinations, same layouts as TfFactors (accumulated with float atomics). */
+typedef struct TfFactorGrads {
+    float* plane[3];
+    float* line[3];
+} TfFactorGrads;
+
+/* Geometry + density field + alpha mask: everything TensorBase.forward reads before shading.
+ * tensorBase.py:52-116 (ctor / update_stepSize), :30-48 (AlphaGridMask). */
+typedef struct TfField {
+    int model;               /* TF_MODEL_* */
+    int act;                 /* TF_ACT_*  (fea2denseAct, tensorBase.py:291-295) */
+    int grid[3];             /* Gx, Gy, Gz */
+    float aabb_lo[3], aabb_hi[3];
+    float inv_aabb[3];       /* 2/(hi-lo), fp32 as tensorBase.py:106 */
+    float near_, far_, step; /* near_far, stepSize (tensorBase.py:109) */
+    float distance_scale, density_shift, weight_thres;
+    TfFactors density;
+    const uint8_t* alpha_cells; /* NULL = no alphaMask */
+    int alpha_grid[3];          /* Gx, Gy, Gz of the alpha volume */
+    float alpha_lo[3];
+    float alpha_inv[3];         /* 1/(hi-lo)*2, fp32 as tensorBase.py:37 */
+} TfField;
+
+/* Inputs/outputs of the ray-march kernel (sampling + masks + density + transmittance scan). */
+typedef struct TfMarchIO {
+    const float* rays;     /* (R,6) */
+    int n_rays, n_samples;
+    int ndc;               /* 0: sample_ray (tensorBase.py:189-208)  1: sample_ray_ndc (:178-187) */
+    const float* jitter;   /* AABB mode: (R) per-ray stratified jitter in [0,1) or NULL (eval) */
+    const float* z_table;  /* NDC mode: (N) z values shared by all rays (linspace [+jitter]) */
+    int save_valid;        /* 1: keep per-ray valid-sample lists for the backward pass */
+    float t_stop;          /* stop marching a ray once transmittance < t_stop (0 = never) */
+    /* per-ray outputs */
+    float* acc;            /* (R) sum of weights                      tensorBase.py:377 */
+    float* depth;          /* (R) sum w*z + (1-acc)*rays[:,-1]        tensorBase.py:386-388 */
+    int* app_offset;       /* (R) first packed app entry of the ray */
+    int* app_count;        /* (R) number of shaded samples of the ray */
+    int* val_count;        /* (R) number of alpha-mask-surviving samples processed */
+    /* sharded counters (TF_N_SHARDS*TF_SHARD_STRIDE ints), zeroed by the caller before launch */
+    int* counters;
+    /* packed app list (capacity TF_N_SHARDS * ceil(R/TF_N_SHARDS) * N entries) */
+    int* app_ray;
+    float* app_xyz;        /* (S,3) normalised coordinates */
+    float* app_w;          /* (S) */
+    /* saved valid lists, dense-strided [r*N + k], only when save_valid */
+    int* val_idx;          /* sample index along the ray */
+    float* val_feat;       /* density feature before activation */
+    /* optional debug bitmaps (R * ceil(N/64) uint64 words) or NULL */
+    uint64_t* dbg_bbox_bits;
+    uint64_t* dbg_valid_bits;
+    uint64_t* dbg_app_bits;   /* must be zeroed by the caller */
+} TfMarchIO;
+
+/* One positional-encoding block of the MLP input (mlp.py:8-13, 41-66, 84-103, 126-153). */
+typedef struct TfPeBlock {
+    int src;               /* TF_SRC_* */
+    int freqs;
+    const float* mask;     /* 2*dim*freqs floats or NULL */
+} TfPeBlock;
+
+/* Appearance field + shading head. */
+typedef struct TfShade {
+    int model;             /* TF_MODEL_* */
+    int grid[3];
+    TfFactors app;
+    int app_dim;
+    int n_app_total;       /* sum of n_comp (VM) or n_comp[0] (CP) */
+    int head;              /* TF_HEAD_* */
+    const float* basis;    /* packed basis_mat: [roundup16(app_dim)][kpad(n_app_total)]   tensoRF.py:149,263 */
+    int n_pe;
+    TfPeBlock pe[3];
+    int in_c;              /* MLP input width (mlp.py:31,75,113) */
+    int feature_c;         /* hidden width: 64, 128 or 256 */
+    const float* w1;       /* packed [feature_c][kpad(in_c)] */
+    const float* b1;
+    const float* w2;       /* packed [feature_c][kpad(feature_c)] */
+    const float* b2;
+    const float* w3;       /* [3][feature_c] */
+    const float* b3;
+} TfShade;
+
+/* kpad(k) = round k up to a multiple of 16 (row stride of every packed matrix = 4 MFMA k-steps). */
+
+/* Builds the 1-byte-per-cell occupancy table from an alpha volume (Gz,Gy,Gx) of non-negative floats.
+ * Replaces the 8-tap trilinear grid_sample of AlphaGridMask.sample_alpha, tensorBase.py:41-45. */
+int tf_pack_alpha_cells(const float* volume, int gx, int gy, int gz, uint8_t* cells, tf_stream_t stream);
+
+/* Zero-pads a row-major (rows, cols) matrix into (rows_pad, kpad(cols)).  Used for basis_mat and the
+ * MLP weights (tensoRF.py:149, mlp.py:34-36). */
+int tf_pack_matrix(const float* src, int rows, int cols, float* dst, int rows_pad, tf_stream_t stream);
+
+/* sample_ray / sample_ray_ndc + bbox test + AlphaGridMask test + compute_densityfeature +
+ * feature2density + raw2alpha + app_mask + acc/depth reductions:
+ * tensorBase.py:178-208, 339-370, 377, 386-388; tensoRF.py:207-227, 358-386. */
+int tf_march_forward(const TfField* field, const TfMarchIO* io, tf_stream_t stream);
+
+/* compute_appfeature + renderModule on the packed app list: tensoRF.py:230-263, 388-415; mlp.py.
+ * counters/seg_cap describe the sharded packed list; rays gives view directions (normalised when ndc,
+ * tensorBase.py:343); rgb_out is (capacity,3), written at the packed positions. */
+int tf_shade_forward(const TfShade* shade, const float* rays, int ndc, const int* counters, int seg_cap,
+                     const int* app_ray, const float* app_xyz, float* rgb_out, tf_stream_t stream);
+
+/* rgb_map = sum w*rgb (+ 1-acc when bg) clamped to [0,1]: tensorBase.py:378-384. */
+int tf_composite_forward(int n_rays, const int* app_offset, const int* app_count, const float* app_w,
+                         const float* rgb, const float* acc, int white_bg, float* rgb_map, tf_stream_t stream);
+
+/* compute_densityfeature / compute_appfeature on an explicit point list (normalised coordinates),
+ * the public hooks used by compute_alpha (tensorBase.py:298-318): out_f (S) / out_feat (S, app_dim). */
+int tf_density_points(const TfField* field, const float* xyz_n, int n, float* out_f, tf_stream_t stream);
+int tf_appfeature_points(const TfShade* shade, const float* xyz_n, int n, float* out_feat, tf_stream_t stream);
+
+/* Backward of compositing + density: consumes d(loss)/d(rgb_map), the saved valid lists and
+ * the per-sample rgb; produces d(loss)/d(rgb sample) for the shading backward and scatter-adds the
+ * density factor gradients. */
+int tf_march_backward(const TfField* field, const TfMarchIO* io, const float* grad_rgb_map, const float* rgb_map,
+                      int white_bg, const float* rgb, float* grad_rgb, const TfFactorGrads* dgrads,
+                      tf_stream_t stream);
+
+/* Backward of the shading head + appearance lookup: recomputes the tile forward, then accumulates
+ * gradients of w1,b1,w2,b2,w3,b3, basis and the appearance factors.  Gradient matrices use the
+ * reference's own (unpadded, row-major) layouts. */
+typedef struct TfShadeGrads {
+    float* w1; float* b1; float* w2; float* b2; float* w3; float* b3;
+    float* basis;          /* (app_dim, n_app_total) */
+    TfFactorGrads app;
+} TfShadeGrads;
+int tf_shade_backward(const TfShade* shade, const float* rays, int ndc, const int* counters, int seg_cap,
+                      const int* app_ray, const float* app_xyz, const float* grad_rgb, const TfShadeGrads* grads,
+                      tf_stream_t stream);
+
+/* Library identification: returns the gfx target string the kernels were compiled for. */
+const char* tf_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TENSORF_HIP_H */
