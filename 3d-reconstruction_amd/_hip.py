@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtensorf_hip.so")
+LIB_PATH = os.path.join(_HERE, "lib", "libtensorf_hip_diag.so" if os.environ.get("TF_DIAG") == "1"
+                        else "libtensorf_hip.so")
 
 N_SHARDS = 64
 SHARD_STRIDE = 32
@@ -76,11 +77,9 @@ _SIGS = {
     "tf_pack_matrix": [_fp, C.c_int, C.c_int, _fp, C.c_int, _fp],
     "tf_march_forward": [C.POINTER(TfField), C.POINTER(TfMarchIO), _fp],
     "tf_shade_forward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp],
-    "tf_composite_forward": [C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp],
+    "tf_composite_forward": [C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp],
     "tf_density_points": [C.POINTER(TfField), _fp, C.c_int, _fp, _fp],
     "tf_appfeature_points": [C.POINTER(TfShade), _fp, C.c_int, _fp, _fp],
-}
-_PENDING = {
     "tf_march_backward": [C.POINTER(TfField), C.POINTER(TfMarchIO), _fp, _fp, C.c_int, _fp, _fp,
                           C.POINTER(TfFactorGrads), _fp],
     "tf_shade_backward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp,

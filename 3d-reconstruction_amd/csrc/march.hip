@@ -228,31 +228,38 @@ __global__ __launch_bounds__(256) void pack_matrix_kernel(const float* __restric
     }
 }
 
-// rgb_map = sum_k w_k rgb_k (+ 1 - acc) clamped  (tensorBase.py:378-384); a ray's entries are contiguous
-// and in sample order, so the sum order is fixed.
+// rgb_map = sum_k w_k rgb_k (+ 1 - acc) clamped  (tensorBase.py:378-384).  8 lanes per ray; a ray's entries
+// are contiguous and in sample order, so the summation order is fixed (deterministic).
 __global__ __launch_bounds__(256) void composite_kernel(int n_rays, const int* __restrict__ app_offset,
                                                         const int* __restrict__ app_count,
                                                         const float* __restrict__ app_w,
                                                         const float* __restrict__ rgb, const float* __restrict__ acc,
-                                                        int white_bg, float* __restrict__ rgb_map) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rays) return;
-    const int o = app_offset[r], c = app_count[r];
-    float cr = 0.f, cg = 0.f, cb = 0.f;
-    for (int k = 0; k < c; ++k) {
-        const float w = app_w[o + k];
-        const float* s = rgb + (size_t)(o + k) * 3;
-        cr += w * s[0];
-        cg += w * s[1];
-        cb += w * s[2];
+                                                        int white_bg, float* __restrict__ rgb_map,
+                                                        float* __restrict__ rgb_pre) {
+    const int r = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+    float c[3] = {0.f, 0.f, 0.f};
+    if (r < n_rays) {
+        const int o = app_offset[r], n = app_count[r];
+        for (int k = sub; k < n; k += 8) {
+            const float w = app_w[o + k];
+            const float* s = rgb + (size_t)(o + k) * 3;
+            c[0] += w * s[0];
+            c[1] += w * s[1];
+            c[2] += w * s[2];
+        }
     }
-    if (white_bg) {
-        const float bg = 1.f - acc[r];
-        cr += bg; cg += bg; cb += bg;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        c[a] += __shfl_xor(c[a], 1, 64);
+        c[a] += __shfl_xor(c[a], 2, 64);
+        c[a] += __shfl_xor(c[a], 4, 64);
     }
-    rgb_map[(size_t)r * 3 + 0] = fminf(fmaxf(cr, 0.f), 1.f);
-    rgb_map[(size_t)r * 3 + 1] = fminf(fmaxf(cg, 0.f), 1.f);
-    rgb_map[(size_t)r * 3 + 2] = fminf(fmaxf(cb, 0.f), 1.f);
+    if (r < n_rays && sub < 3) {
+        float v = sub == 0 ? c[0] : (sub == 1 ? c[1] : c[2]);
+        if (white_bg) v += 1.f - acc[r];
+        if (rgb_pre) rgb_pre[(size_t)r * 3 + sub] = v;
+        rgb_map[(size_t)r * 3 + sub] = fminf(fmaxf(v, 0.f), 1.f);
+    }
 }
 
 }  // namespace
@@ -285,10 +292,11 @@ int tf_march_forward(const TfField* field, const TfMarchIO* io, tf_stream_t stre
 }
 
 int tf_composite_forward(int n_rays, const int* app_offset, const int* app_count, const float* app_w,
-                         const float* rgb, const float* acc, int white_bg, float* rgb_map, tf_stream_t stream) {
+                         const float* rgb, const float* acc, int white_bg, float* rgb_map, float* rgb_pre,
+                         tf_stream_t stream) {
     if (n_rays <= 0) return 0;
-    hipLaunchKernelGGL(composite_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_rays,
-                       app_offset, app_count, app_w, rgb, acc, white_bg, rgb_map);
+    hipLaunchKernelGGL(composite_kernel, dim3((n_rays + 31) / 32), dim3(256), 0, (hipStream_t)stream, n_rays,
+                       app_offset, app_count, app_w, rgb, acc, white_bg, rgb_map, rgb_pre);
     return TF_CHECK_LAUNCH();
 }
 

@@ -1,0 +1,178 @@
+// tf_shade.h — pieces shared by the shading forward (shade.hip) and backward (shade_bwd.hip) kernels.
+#pragma once
+#include "tf_device.h"
+
+namespace tf {
+
+constexpr int M = TF_TILE;
+
+// Diagnostic build only (-DTF_PHASE_TIMING, lib/libtensorf_hip_diag.so): per-phase shader-clock totals.
+#ifdef TF_PHASE_TIMING
+static __device__ unsigned long long tf_phase_cycles[16];
+#define TF_T0() unsigned long long _t = __builtin_readcyclecounter(); unsigned long long _ph[8] = {0,0,0,0,0,0,0,0}
+#define TF_MARK(i) do { unsigned long long _n = __builtin_readcyclecounter(); _ph[i] += _n - _t; _t = _n; } while (0)
+#define TF_FLUSH() do { if (threadIdx.x == 0) for (int _i = 0; _i < 8; ++_i) atomicAdd(&tf_phase_cycles[_i], _ph[_i]); } while (0)
+#else
+#define TF_T0()
+#define TF_MARK(i)
+#define TF_FLUSH()
+#endif
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline int kpad16(int k) { return (k + 15) & ~15; }
+
+struct ShadeLds {   // strides in floats; all regions carved from one dynamic LDS array
+    int sv, sx, sh;       // row strides of V, X, H
+    int offA, offB, offInfo, offPre;
+    int total;            // floats
+};
+__host__ __device__ inline ShadeLds shade_lds(const TfShade& S) {
+    ShadeLds L;
+    L.sv = kpad16(S.n_app_total) + 4;
+    const int xin = S.head == TF_HEAD_MLP ? S.in_c : S.app_dim + 3;
+    L.sx = kpad16(xin > S.app_dim + 3 ? xin : S.app_dim + 3) + 4;
+    L.sh = (S.head == TF_HEAD_MLP ? S.feature_c : 0) + 4;
+    const int a = L.sv > L.sh ? L.sv : L.sh, b = L.sx > L.sh ? L.sx : L.sh;
+    L.offA = 0;
+    L.offB = M * a;
+    L.offInfo = L.offB + M * b;
+    L.offPre = L.offInfo + M * 8;           // tile prefix over shards (65 ints)
+    L.total = L.offPre + 80;
+    return L;
+}
+
+// The wave computes D[f][s] += sum_k W[f][k] * X[s][k] for feature tiles f_base+16a (a<NF) and sample
+// tiles s_base+16b (b<NS).  W: global, row stride ldw (multiple of 16, zero padded); X: LDS, stride ldx.
+// Lane (r = lane&15, kq = lane>>4) loads W[f][16kg+4kq..+3] and X[s][16kg+4kq..+3]; MFMA step e uses
+// element e of both, i.e. k = 16kg+4kq+e on both operands.  D: row(feature) = 4*(lane>>4)+reg, col(sample) = lane&15.
+template <int NF, int NS>
+__device__ __forceinline__ void mma_block(const float* __restrict__ Wg, int ldw, int f_base, const float* Xs, int ldx,
+                                          int s_base, int kgroups, f32x4 (&acc)[NF][NS]) {
+    const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
+    const float* wp = Wg + (size_t)(f_base + r) * ldw + 4 * kq;
+    const float* xp = Xs + (s_base + r) * ldx + 4 * kq;
+#pragma unroll 2
+    for (int kg = 0; kg < kgroups; ++kg) {
+        f32x4 a[NF], b[NS];
+#pragma unroll
+        for (int i = 0; i < NF; ++i) a[i] = *reinterpret_cast<const f32x4*>(wp + (size_t)16 * i * ldw + 16 * kg);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) b[j] = *reinterpret_cast<const f32x4*>(xp + 16 * j * ldx + 16 * kg);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+#pragma unroll
+                for (int j = 0; j < NS; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+    }
+}
+
+// Products (P*m)(L*m) [VM] or (L0*L1*L2)*m [CP] of one sample, channel quads sub, sub+4, ..., written to
+// vrow[0 .. n_app_total).
+__device__ __forceinline__ void app_products(const TfShade& S, const float u[3], int sub, float* vrow) {
+    if (S.model == TF_MODEL_VM) {
+        VmTaps t;
+        make_vm_taps(S.grid, u, t);
+        int coff = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int C = S.app.n_comp[i];
+            const float* mk = S.app.mask[i];
+            if ((C & 3) == 0 && (coff & 3) == 0) {
+                for (int q = sub; q < (C >> 2); q += 4) {
+                    float4_t p = bilerp4(S.app.plane[i], C, t.p[i], q * 4);
+                    float4_t l = lerp4(S.app.line[i], C, t.l[i], q * 4);
+                    if (mk) {
+                        float4_t m = ld4(mk + q * 4);
+                        p *= m;
+                        l *= m;
+                    }
+                    *reinterpret_cast<float4_t*>(vrow + coff + q * 4) = p * l;
+                }
+            } else {
+                for (int c = sub; c < C; c += 4) {
+                    float p = bilerp1(S.app.plane[i], C, t.p[i], c);
+                    float l = lerp1(S.app.line[i], C, t.l[i], c);
+                    if (mk) {
+                        p *= mk[c];
+                        l *= mk[c];
+                    }
+                    vrow[coff + c] = p * l;
+                }
+            }
+            coff += C;
+        }
+    } else {
+        const int C = S.app.n_comp[0];
+        Tap1 t0 = make_tap1(u[vecm(0)], S.grid[vecm(0)]);
+        Tap1 t1 = make_tap1(u[vecm(1)], S.grid[vecm(1)]);
+        Tap1 t2 = make_tap1(u[vecm(2)], S.grid[vecm(2)]);
+        const float* mk = S.app.mask[0];
+        if ((C & 3) == 0) {
+            for (int q = sub; q < (C >> 2); q += 4) {
+                float4_t v = lerp4(S.app.line[0], C, t0, q * 4);
+                v *= lerp4(S.app.line[1], C, t1, q * 4);
+                v *= lerp4(S.app.line[2], C, t2, q * 4);
+                if (mk) v *= ld4(mk + q * 4);
+                *reinterpret_cast<float4_t*>(vrow + q * 4) = v;
+            }
+        } else {
+            for (int c = sub; c < C; c += 4) {
+                float v = lerp1(S.app.line[0], C, t0, c) * lerp1(S.app.line[1], C, t1, c);
+                v *= lerp1(S.app.line[2], C, t2, c);
+                if (mk) v *= mk[c];
+                vrow[c] = v;
+            }
+        }
+    }
+}
+
+// real SH basis, degree 2 (sh.py:87-112)
+__device__ __forceinline__ void sh9(const float d[3], float y[9]) {
+    const float x = d[0], yy_ = d[1], z = d[2];
+    y[0] = 0.28209479177387814f;
+    y[1] = -0.4886025119029199f * yy_;
+    y[2] = 0.4886025119029199f * z;
+    y[3] = -0.4886025119029199f * x;
+    const float xx = x * x, yy = yy_ * yy_, zz = z * z;
+    y[4] = 1.0925484305920792f * (x * yy_);
+    y[5] = -1.0925484305920792f * (yy_ * z);
+    y[6] = 0.31539156525252005f * (2.0f * zz - xx - yy);
+    y[7] = -1.0925484305920792f * (x * z);
+    y[8] = 0.5462742152960396f * (xx - yy);
+}
+
+struct TileSrc {          // where a tile's samples come from
+    const int* counters;  // sharded packed list (NULL in direct mode)
+    int seg_cap;
+    int n_direct;         // direct mode: a plain point list of this many entries
+    const int* app_ray;
+    const float* app_xyz;
+    const float* rays;
+    int ndc;
+};
+
+// Enumerates the tiles of all shards: returns false when t is past the last tile.
+__device__ __forceinline__ bool locate_tile(const TileSrc& src, const int* pre /*LDS prefix[65]*/, int t, int& s0,
+                                            int& n) {
+    if (src.counters == nullptr) {
+        s0 = t * M;
+        n = min(M, src.n_direct - s0);
+        return n > 0;
+    }
+    if (t >= pre[TF_N_SHARDS]) return false;
+    int lo = 0, hi = TF_N_SHARDS - 1;   // last g with pre[g] <= t
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (pre[mid] <= t) lo = mid; else hi = mid - 1;
+    }
+    const int lt = t - pre[lo];
+    const int cnt = src.counters[lo * TF_SHARD_STRIDE];
+    s0 = lo * src.seg_cap + lt * M;
+    n = min(M, cnt - lt * M);
+    return true;
+}
+
+
+}  // namespace tf

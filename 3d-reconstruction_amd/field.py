@@ -152,7 +152,7 @@ class _Workspace:
                 ("app_xyz", cap * 3, torch.float32), ("rgb", cap * 3, torch.float32)]
         if save_valid:
             spec += [("val_idx", R * N, torch.int32), ("val_feat", R * N, torch.float32),
-                     ("grad_rgb", cap * 3, torch.float32)]
+                     ("grad_rgb", cap * 3, torch.float32), ("rgb_pre", R * 3, torch.float32)]
         if debug:
             spec += [("dbg_bbox", R * words * 2, torch.int32), ("dbg_valid", R * words * 2, torch.int32),
                      ("dbg_app", R * words * 2, torch.int32)]
@@ -514,7 +514,8 @@ class TensorBase(nn.Module):
                                      ws.seg_cap, ws.app_ray.data_ptr(), ws.app_xyz.data_ptr(), ws.rgb.data_ptr(), st),
                 "tf_shade_forward")
         H.check(lib.tf_composite_forward(R, ws.app_offset.data_ptr(), ws.app_count.data_ptr(), ws.app_w.data_ptr(),
-                                         ws.rgb.data_ptr(), ws.acc.data_ptr(), int(use_bg), ws.rgb_map.data_ptr(), st),
+                                         ws.rgb.data_ptr(), ws.acc.data_ptr(), int(use_bg), ws.rgb_map.data_ptr(),
+                                         ws.rgb_pre.data_ptr() if save_valid else None, st),
                 "tf_composite_forward")
         ctx = dict(ws=ws, rays=rays, field=field, shade=shade, io=io, keep=(keep, den_masks, app_masks, jitter, ztab),
                    use_bg=use_bg, ndc=bool(ndc_ray))

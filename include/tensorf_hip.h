@@ -155,9 +155,11 @@ int tf_march_forward(const TfField* field, const TfMarchIO* io, tf_stream_t stre
 int tf_shade_forward(const TfShade* shade, const float* rays, int ndc, const int* counters, int seg_cap,
                      const int* app_ray, const float* app_xyz, float* rgb_out, tf_stream_t stream);
 
-/* rgb_map = sum w*rgb (+ 1-acc when bg) clamped to [0,1]: tensorBase.py:378-384. */
+/* rgb_map = sum w*rgb (+ 1-acc when bg) clamped to [0,1]: tensorBase.py:378-384.  rgb_pre (optional)
+ * receives the pre-clamp value, which the backward needs for the clamp mask. */
 int tf_composite_forward(int n_rays, const int* app_offset, const int* app_count, const float* app_w,
-                         const float* rgb, const float* acc, int white_bg, float* rgb_map, tf_stream_t stream);
+                         const float* rgb, const float* acc, int white_bg, float* rgb_map, float* rgb_pre,
+                         tf_stream_t stream);
 
 /* compute_densityfeature / compute_appfeature on an explicit point list (normalised coordinates),
  * the public hooks used by compute_alpha (tensorBase.py:298-318): out_f (S) / out_feat (S, app_dim). */
@@ -167,7 +169,7 @@ int tf_appfeature_points(const TfShade* shade, const float* xyz_n, int n, float*
 /* Backward of compositing + density: consumes d(loss)/d(rgb_map), the saved valid lists and
  * the per-sample rgb; produces d(loss)/d(rgb sample) for the shading backward and scatter-adds the
  * density factor gradients. */
-int tf_march_backward(const TfField* field, const TfMarchIO* io, const float* grad_rgb_map, const float* rgb_map,
+int tf_march_backward(const TfField* field, const TfMarchIO* io, const float* grad_rgb_map, const float* rgb_pre,
                       int white_bg, const float* rgb, float* grad_rgb, const TfFactorGrads* dgrads,
                       tf_stream_t stream);
 
