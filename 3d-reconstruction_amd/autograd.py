@@ -31,7 +31,7 @@ def _grad_buffers(named):
             out[name] = chunk.view(b, h, w, c).permute(0, 3, 1, 2)
         else:
             out[name] = chunk.view(p.shape)
-    return out
+    return out, flat
 
 
 class _RenderFn(torch.autograd.Function):
@@ -58,7 +58,8 @@ class _RenderFn(torch.autograd.Function):
         ws = c['ws']
         st = _stream()
         named = list(zip(names, ctx.params))
-        grads = _grad_buffers(named)
+        grads, flat = _grad_buffers(named)
+        model.grad_flat = flat      # all parameter gradients of this step, one contiguous buffer (parallel.py)
         g = g_rgb.detach().to(torch.float32).contiguous()
         cp = model._is_cp()
 
@@ -70,18 +71,17 @@ class _RenderFn(torch.autograd.Function):
                 ag.plane[i] = grads[f'app_plane.{i}'].data_ptr()
             dg.line[i] = grads[f'density_line.{i}'].data_ptr()
             ag.line[i] = grads[f'app_line.{i}'].data_ptr()
-        H.check(lib.tf_march_backward(C.byref(c['field']), C.byref(c['io']), g.data_ptr(), ws.rgb_pre.data_ptr(),
-                                      int(c['use_bg']), ws.rgb.data_ptr(), ws.grad_rgb.data_ptr(), C.byref(dg), st),
-                "tf_march_backward")
+        model._timed("tf_march_backward", lib.tf_march_backward, C.byref(c['field']), C.byref(c['io']), g.data_ptr(),
+                     ws.rgb_pre.data_ptr(), int(c['use_bg']), ws.rgb.data_ptr(), ws.grad_rgb.data_ptr(), C.byref(dg), st)
         sg = H.TfShadeGrads()
         sg.w1, sg.b1 = grads['renderModule.mlp.0.weight'].data_ptr(), grads['renderModule.mlp.0.bias'].data_ptr()
         sg.w2, sg.b2 = grads['renderModule.mlp.2.weight'].data_ptr(), grads['renderModule.mlp.2.bias'].data_ptr()
         sg.w3, sg.b3 = grads['renderModule.mlp.4.weight'].data_ptr(), grads['renderModule.mlp.4.bias'].data_ptr()
         sg.basis = grads['basis_mat.weight'].data_ptr()
         sg.app = ag
-        H.check(lib.tf_shade_backward(C.byref(c['shade']), c['rays'].data_ptr(), int(c['ndc']), ws.counters.data_ptr(),
-                                      ws.seg_cap, ws.app_ray.data_ptr(), ws.app_xyz.data_ptr(), ws.grad_rgb.data_ptr(),
-                                      C.byref(sg), st), "tf_shade_backward")
+        model._timed("tf_shade_backward", lib.tf_shade_backward, C.byref(c['shade']), c['rays'].data_ptr(),
+                     int(c['ndc']), ws.counters.data_ptr(), ws.seg_cap, ws.app_ray.data_ptr(), ws.app_xyz.data_ptr(),
+                     ws.grad_rgb.data_ptr(), C.byref(sg), st)
         out = tuple(grads[n] if p.requires_grad else None for n, p in named)
         ctx.c = None
         return (None,) * 8 + out

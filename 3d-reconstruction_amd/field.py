@@ -208,6 +208,7 @@ class TensorBase(nn.Module):
         self._pack_cache = {}
         self._ztab_cache = {}
         self.last = None               # workspace of the most recent forward (tests / bench statistics)
+        self.kernel_events = None      # bench: dict name -> [(start_event, end_event)] when enabled
 
         self.init_render_func(self.shadingMode, self.pos_pe, self.view_pe, self.fea_pe, self.featureC, device)
         self.update_stepSize(gridSize)
@@ -467,6 +468,19 @@ class TensorBase(nn.Module):
                 self._ws_cache = {key: ws}
         return ws
 
+    def _timed(self, name, fn, *args):
+        """Runs one C-ABI launch; when `kernel_events` is a dict, brackets it with HIP events recorded on the
+        launch stream (torch's current stream) so bench.py can read per-kernel durations."""
+        ev = self.kernel_events
+        if ev is None:
+            H.check(fn(*args), name)
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        H.check(fn(*args), name)
+        b.record()
+        ev.setdefault(name, []).append((a, b))
+
     # ---- forward -------------------------------------------------------------------------------
     def _run_forward(self, rays, mask, white_bg, is_train, ndc_ray, N_samples, save_valid):
         lib = H.lib()
@@ -509,14 +523,13 @@ class TensorBase(nn.Module):
             ws.dbg_app.zero_()
             io.dbg_bbox_bits, io.dbg_valid_bits = ws.dbg_bbox.data_ptr(), ws.dbg_valid.data_ptr()
             io.dbg_app_bits = ws.dbg_app.data_ptr()
-        H.check(lib.tf_march_forward(C.byref(field), C.byref(io), st), "tf_march_forward")
-        H.check(lib.tf_shade_forward(C.byref(shade), rays.data_ptr(), int(bool(ndc_ray)), ws.counters.data_ptr(),
-                                     ws.seg_cap, ws.app_ray.data_ptr(), ws.app_xyz.data_ptr(), ws.rgb.data_ptr(), st),
-                "tf_shade_forward")
-        H.check(lib.tf_composite_forward(R, ws.app_offset.data_ptr(), ws.app_count.data_ptr(), ws.app_w.data_ptr(),
-                                         ws.rgb.data_ptr(), ws.acc.data_ptr(), int(use_bg), ws.rgb_map.data_ptr(),
-                                         ws.rgb_pre.data_ptr() if save_valid else None, st),
-                "tf_composite_forward")
+        self._timed("tf_march_forward", lib.tf_march_forward, C.byref(field), C.byref(io), st)
+        self._timed("tf_shade_forward", lib.tf_shade_forward, C.byref(shade), rays.data_ptr(), int(bool(ndc_ray)),
+                    ws.counters.data_ptr(), ws.seg_cap, ws.app_ray.data_ptr(), ws.app_xyz.data_ptr(),
+                    ws.rgb.data_ptr(), st)
+        self._timed("tf_composite_forward", lib.tf_composite_forward, R, ws.app_offset.data_ptr(),
+                    ws.app_count.data_ptr(), ws.app_w.data_ptr(), ws.rgb.data_ptr(), ws.acc.data_ptr(), int(use_bg),
+                    ws.rgb_map.data_ptr(), ws.rgb_pre.data_ptr() if save_valid else None, st)
         ctx = dict(ws=ws, rays=rays, field=field, shade=shade, io=io, keep=(keep, den_masks, app_masks, jitter, ztab),
                    use_bg=use_bg, ndc=bool(ndc_ray))
         self.last = ctx

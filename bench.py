@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""bench.py — rays/s of the TensoRF ray-marching hot path on MI355X (BASELINE.json metric).
+
+Workload (`config.workload`): BASELINE config 2 — TensorVMSplit, 300^3 grid, density_n_comp [16,16,16],
+app_n_comp [48,48,48], app_dim 27, MLP_Fea shading, N = 1039 samples/ray, batches of 4096 rays drawn (seeded
+permutation, SimpleSampler-style) from synthetic Blender-Lego 800x800 views, 'trained-like' field state
+(no dataset or checkpoint exists offline).
+
+A "step" is what train.py:323-376 does per iteration on this path: renderer(...) forward -> MSE ->
+backward -> Adam step, on one 4096-ray batch per GPU (weak scaling: the global batch is 4096 x n_gpus,
+gradients all-reduced over RCCL).  `--mode eval` times the forward-only renderer instead.
+
+    python bench.py [--gpus N --steps K --warmup W --mode train|eval]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Extra objects: `roofline` (dominant kernel, durations measured live with HIP
+events on the launch stream), `kernels` (all five kernels), `cpu_baseline` (the CPU oracle = plain-PyTorch
+restatement of the reference, timed on this box's host cores) and `rocm_eager_baseline` (the same
+restatement run with device='cuda' = the reference's PyTorch-ROCm path).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_MFMA_PEAK_TF = 157.3    # dense fp32 matrix peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--mode", choices=["train", "eval"], default="train")
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--grid", type=int, default=300)
+    ap.add_argument("--views", type=int, default=3)
+    ap.add_argument("--no-baselines", action="store_true", help="skip the CPU / ROCm-eager baseline legs")
+    return ap.parse_args()
+
+
+def build_scene(recon, dev, grid, views, seed=0):
+    from recon_amd import synthetic as S
+    torch.manual_seed(seed)
+    aabb = torch.tensor(S.LEGO_AABB, device=dev)
+    reso = recon.N_to_reso(grid ** 3, aabb)
+    model = recon.TensorVMSplit(S.lego_args(), aabb, reso, S.LEGO_NEAR_FAR, dev)
+    S.make_trained_like(model, recon.AlphaGridMask)
+    n_samples = min(int(1e6), recon.cal_n_samples(reso, 0.5))        # train.py:208
+    rays = S.blender_rays(views)
+    keep = S.bbox_hit_mask(rays, aabb.cpu())                          # filtering_rays(bbox_only=True), train.py:291
+    rays = rays[keep].to(dev)
+    g = torch.Generator().manual_seed(seed + 1)
+    targets = torch.rand(rays.shape[0], 3, generator=g).to(dev)
+    return model, rays, targets, n_samples, reso
+
+
+def kernel_table(events, stats, cfg):
+    """Average duration per kernel + algorithmic bytes / flops per launch (SURVEY §8d figures)."""
+    R, Sb, Ss, Sa = stats["rays"], stats["bbox"], stats["density"], stats["shaded"]
+    cd, ca = sum(cfg["density_n_comp"]), sum(cfg["app_n_comp"])
+    mlp_flops = 2 * (cfg["in_c"] * cfg["featureC"] + cfg["featureC"] ** 2 + cfg["featureC"] * 3) + 2 * ca * cfg["app_dim"]
+    bwd_flops = 2 * mlp_flops + mlp_flops      # weight-gradient + input-gradient GEMMs + forward recompute
+    algo = {
+        "tf_march_forward": (R * 40 + 32 * Sb + 24 * cd * Ss, 0.0),
+        "tf_shade_forward": (24 * ca * Sa, mlp_flops * Sa),
+        "tf_composite_forward": (R * 16 + 16 * Sa, 0.0),
+        "tf_march_backward": (2 * 24 * cd * Ss + 8 * Ss, 0.0),
+        "tf_shade_backward": (2 * 24 * ca * Sa, bwd_flops * Sa),
+    }
+    out = {}
+    for name, pairs in events.items():
+        ms = sum(a.elapsed_time(b) for a, b in pairs) / max(len(pairs), 1)
+        by, fl = algo.get(name, (0.0, 0.0))
+        out[name] = {"avg_ms": ms, "launches": len(pairs), "algo_bytes": by, "algo_flops": fl,
+                     "GBps": by / ms / 1e6 if ms > 0 else 0.0, "TFLOPps": fl / ms / 1e9 if ms > 0 else 0.0}
+    return out
+
+
+def oracle_baseline(model, rays_cpu, targets_cpu, n_samples, device, mode, steps, warmup):
+    """The plain-PyTorch restatement of the reference path (oracle/ref_torch.py) as a timed baseline."""
+    from oracle import ref_torch as R
+    dev = torch.device(device)
+    cfg = R.FieldCfg(model="TensorVMSplit", aabb=model.aabb.detach().to(dev), gridSize=model.gridSize.tolist(),
+                     near_far=model.near_far, step_ratio=model.step_ratio, fea2denseAct=model.fea2denseAct,
+                     density_n_comp=model.density_n_comp, app_n_comp=model.app_n_comp, app_dim=model.app_dim,
+                     density_shift=model.density_shift, distance_scale=model.distance_scale,
+                     shadingMode=model.shadingMode, pos_pe=model.pos_pe, view_pe=model.view_pe, fea_pe=model.fea_pe,
+                     featureC=model.featureC).finalize()
+    cfg.alpha_volume = model.alphaMask.alpha_volume[0, 0].to(dev)
+    cfg.alpha_aabb = model.alphaMask.aabb.to(dev)
+    params = {k: v.detach().to(dev).contiguous().clone().requires_grad_(mode == "train")
+              for k, v in model.state_dict().items()}
+    opt = torch.optim.Adam(list(params.values()), lr=1e-3, betas=(0.9, 0.99)) if mode == "train" else None
+    B = rays_cpu.shape[0] // (steps + warmup)
+    times = []
+    for i in range(steps + warmup):
+        r = rays_cpu[i * B:(i + 1) * B].to(dev)
+        t = targets_cpu[i * B:(i + 1) * B].to(dev)
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if mode == "train":
+            rgb, _, _ = R.render_rays(cfg, params, r, None, white_bg=True, is_train=True, n_samples=n_samples)
+            loss = torch.mean((rgb - t) ** 2)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        else:
+            with torch.no_grad():
+                R.render_rays(cfg, params, r, None, white_bg=True, is_train=False, n_samples=n_samples)
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        if i >= warmup:
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return B / med, B, len(times)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    import recon_amd
+    from recon_amd import parallel
+    model, rays, targets, n_samples, reso = build_scene(recon_amd, dev, args.grid, args.views)
+    B = args.batch
+    n_steps = args.steps + args.warmup
+    g = torch.Generator().manual_seed(20211202)
+    perm = torch.randperm(rays.shape[0], generator=g)
+    need = B * world * n_steps
+    if perm.numel() < need:
+        perm = perm.repeat((need + perm.numel() - 1) // perm.numel())
+    perm = perm[:need].view(n_steps, B * world).to(dev)
+
+    opt = torch.optim.Adam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+    renderer = recon_amd.OctreeRender_trilinear_fast
+
+    def train_step(i):
+        ids = parallel.shard_ids(perm[i], rank, world)
+        rays_train, rgb_train = rays[ids], targets[ids]
+        rgb_map, _, depth_map, _, _, n = renderer(rays_train, model, None, chunk=B, N_samples=n_samples, white_bg=True,
+                                                   ndc_ray=False, device=dev, is_train=True)
+        loss = torch.mean((rgb_map - rgb_train) ** 2)
+        opt.zero_grad()
+        loss.backward()
+        parallel.allreduce_gradients(model)
+        opt.step()
+        return loss
+
+    def eval_step(i):
+        ids = parallel.shard_ids(perm[i], rank, world)
+        with torch.no_grad():
+            renderer(rays[ids], model, None, chunk=B, N_samples=n_samples, white_bg=True, ndc_ray=False, device=dev,
+                     is_train=False)
+
+    step = train_step if args.mode == "train" else eval_step
+    torch.manual_seed(1234 + rank)
+    for i in range(args.warmup):
+        step(i)
+    model.kernel_events = {}
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stats = {"rays": 0, "bbox": 0, "density": 0, "shaded": 0}
+    ctr_sum = torch.zeros(3, dtype=torch.int64, device=dev)
+    for i in range(args.warmup, n_steps):
+        step(i)
+        ctr_sum += model.last["ws"].counters2d[:, :3].sum(0)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+    events = model.kernel_events
+    model.kernel_events = None
+
+    if rank == 0:
+        k = args.steps
+        c = ctr_sum.tolist()
+        stats = {"rays": B, "shaded": c[0] / k, "density": c[1] / k, "bbox": c[2] / k}
+        cfg = dict(density_n_comp=model.density_n_comp, app_n_comp=model.app_n_comp, app_dim=model.app_dim,
+                   featureC=model.featureC, in_c=model.renderModule.in_mlpC)
+        kt = kernel_table(events, stats, cfg)
+        dom = max(kt, key=lambda n: kt[n]["avg_ms"])
+        d = kt[dom]
+        hbm_frac = d["GBps"] / HBM_PEAK_GBS
+        mfma_frac = d["TFLOPps"] / FP32_MFMA_PEAK_TF
+        if mfma_frac > hbm_frac:
+            roof = {"kernel": dom, "bound": "mfma", "achieved": d["TFLOPps"], "peak": FP32_MFMA_PEAK_TF,
+                    "unit": "TFLOP/s", "frac": mfma_frac, "traffic": None, "avg_launch_ms": d["avg_ms"]}
+        else:
+            roof = {"kernel": dom, "bound": "hbm", "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": hbm_frac, "traffic": None, "avg_launch_ms": d["avg_ms"]}
+        value = B * world * k / elapsed
+        line = {
+            "metric": f"rays/sec ({args.mode}), Lego 800^2 @ {args.grid}^3 grid",
+            "value": value, "unit": "rays/s", "n_gpus": world, "steps": k, "warmup": args.warmup,
+            "ms_per_step": elapsed / k * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"TensorVMSplit {reso} grid, [16,16,16]/[48,48,48] comps, MLP_Fea, N={n_samples}, "
+                                   f"{B}-ray batch per GPU, {args.mode} step"
+                                   + (" = fwd+bwd+Adam" if args.mode == "train" else " = renderer forward"),
+                       "mode": args.mode, "batch_per_gpu": B, "global_batch": B * world, "n_samples": n_samples,
+                       "per_ray": {"in_bbox": stats["bbox"] / B, "density": stats["density"] / B,
+                                   "shaded": stats["shaded"] / B},
+                       "parallelism": f"ray-sharded dp{world}"},
+            "roofline": roof,
+            "kernels": {n: {"avg_ms": round(v["avg_ms"], 5), "GBps": round(v["GBps"], 1),
+                            "TFLOPps": round(v["TFLOPps"], 2)} for n, v in kt.items()},
+        }
+        if not args.no_baselines and world == 1:
+            cores = os.cpu_count()
+            torch.set_num_threads(cores)
+            steps_cpu, warm_cpu = 3, 1
+            need_cpu = B * (steps_cpu + warm_cpu)
+            idx = perm.reshape(-1)[:need_cpu]
+            v, bs, ns = oracle_baseline(model, rays[idx].cpu(), targets[idx].cpu(), n_samples, "cpu", args.mode,
+                                        steps_cpu, warm_cpu)
+            line["cpu_baseline"] = {"value": v, "unit": "rays/s", "cores": cores, "kind": "port",
+                                    "sample": f"median of {ns} {args.mode} steps of {bs} rays (same scene, same N), "
+                                              f"oracle/ref_torch.py on CPU, {cores} torch threads"}
+            steps_g, warm_g = 5, 2
+            idx = perm.reshape(-1)[:B * (steps_g + warm_g)]
+            v2, bs2, ns2 = oracle_baseline(model, rays[idx], targets[idx], n_samples, str(dev), args.mode, steps_g, warm_g)
+            line["rocm_eager_baseline"] = {"value": v2, "unit": "rays/s",
+                                           "sample": f"median of {ns2} {args.mode} steps of {bs2} rays, the same "
+                                                     f"restatement run eagerly on this GPU (PyTorch-ROCm path)",
+                                           "speedup": value / v2}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
