@@ -28,7 +28,7 @@ class TfFactors(C.Structure):
 
 
 class TfFactorGrads(C.Structure):
-    _fields_ = [("plane", _fp * 3), ("line", _fp * 3)]
+    _fields_ = [("plane", _fp * 3), ("line", _fp * 3), ("n_rep", C.c_int), ("rep_stride", C.c_int)]
 
 
 class TfField(C.Structure):
@@ -80,6 +80,7 @@ _SIGS = {
     "tf_composite_forward": [C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp],
     "tf_density_points": [C.POINTER(TfField), _fp, C.c_int, _fp, _fp],
     "tf_appfeature_points": [C.POINTER(TfShade), _fp, C.c_int, _fp, _fp],
+    "tf_reduce_replicas": [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp],
     "tf_march_backward": [C.POINTER(TfField), C.POINTER(TfMarchIO), _fp, _fp, C.c_int, _fp, _fp,
                           C.POINTER(TfFactorGrads), _fp],
     "tf_shade_backward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp,

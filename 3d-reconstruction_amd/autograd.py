@@ -14,24 +14,30 @@ from . import _hip as H
 from .field import _stream, is_channel_last
 
 
+N_REP = 64   # replicas of the line-gradient tensors (TfFactorGrads.n_rep)
+
+
 def _grad_buffers(named):
-    """One zero-filled allocation carved into per-parameter gradient views (factor tensors channel-last)."""
-    sizes = [p.numel() for _, p in named]
-    offs, total = [], 0
-    for n in sizes:
-        offs.append(total)
-        total += (n + 63) // 64 * 64
-    dev = named[0][1].device
-    flat = torch.zeros(total, dtype=torch.float32, device=dev)
-    out = {}
-    for (name, p), off, n in zip(named, offs, sizes):
-        chunk = flat[off:off + n]
+    """One zero-filled allocation: [line gradients | all other gradients | N_REP replicas of the line block].
+    The kernels scatter line gradients into the replicas; tf_reduce_replicas folds them into the head of
+    the buffer, so flat[:grad_len] is every parameter gradient of the step, contiguous (one all-reduce)."""
+    named = sorted(named, key=lambda kv: 0 if '_line.' in kv[0] else 1)
+    offs, total, line_len = {}, 0, 0
+    for name, p in named:
+        offs[name] = total
+        total += (p.numel() + 63) // 64 * 64
+        if '_line.' in name:
+            line_len = total
+    flat = torch.zeros(total + N_REP * line_len, dtype=torch.float32, device=named[0][1].device)
+    views = {}
+    for name, p in named:
+        chunk = flat[offs[name]:offs[name] + p.numel()]
         if p.dim() == 4 and is_channel_last(p):
             b, c, h, w = p.shape
-            out[name] = chunk.view(b, h, w, c).permute(0, 3, 1, 2)
+            views[name] = chunk.view(b, h, w, c).permute(0, 3, 1, 2)
         else:
-            out[name] = chunk.view(p.shape)
-    return out, flat
+            views[name] = chunk.view(p.shape)
+    return views, flat, offs, total, line_len
 
 
 class _RenderFn(torch.autograd.Function):
@@ -58,19 +64,20 @@ class _RenderFn(torch.autograd.Function):
         ws = c['ws']
         st = _stream()
         named = list(zip(names, ctx.params))
-        grads, flat = _grad_buffers(named)
-        model.grad_flat = flat      # all parameter gradients of this step, one contiguous buffer (parallel.py)
+        grads, flat, offs, grad_len, line_len = _grad_buffers(named)
+        model.grad_flat = flat[:grad_len]   # every gradient of this step, one contiguous buffer (parallel.py)
         g = g_rgb.detach().to(torch.float32).contiguous()
         cp = model._is_cp()
+        rep0 = flat.data_ptr() + 4 * grad_len          # replica 0 of the line block
 
         dg = H.TfFactorGrads()
         ag = H.TfFactorGrads()
-        for i in range(3):
-            if not cp:
-                dg.plane[i] = grads[f'density_plane.{i}'].data_ptr()
-                ag.plane[i] = grads[f'app_plane.{i}'].data_ptr()
-            dg.line[i] = grads[f'density_line.{i}'].data_ptr()
-            ag.line[i] = grads[f'app_line.{i}'].data_ptr()
+        for fg, kind in ((dg, 'density'), (ag, 'app')):
+            fg.n_rep, fg.rep_stride = N_REP, line_len
+            for i in range(3):
+                if not cp:
+                    fg.plane[i] = grads[f'{kind}_plane.{i}'].data_ptr()
+                fg.line[i] = rep0 + 4 * offs[f'{kind}_line.{i}']
         model._timed("tf_march_backward", lib.tf_march_backward, C.byref(c['field']), C.byref(c['io']), g.data_ptr(),
                      ws.rgb_pre.data_ptr(), int(c['use_bg']), ws.rgb.data_ptr(), ws.grad_rgb.data_ptr(), C.byref(dg), st)
         sg = H.TfShadeGrads()
@@ -82,6 +89,7 @@ class _RenderFn(torch.autograd.Function):
         model._timed("tf_shade_backward", lib.tf_shade_backward, C.byref(c['shade']), c['rays'].data_ptr(),
                      int(c['ndc']), ws.counters.data_ptr(), ws.seg_cap, ws.app_ray.data_ptr(), ws.app_xyz.data_ptr(),
                      ws.grad_rgb.data_ptr(), C.byref(sg), st)
+        model._timed("tf_reduce_replicas", lib.tf_reduce_replicas, rep0, N_REP, line_len, line_len, flat.data_ptr(), st)
         out = tuple(grads[n] if p.requires_grad else None for n, p in named)
         ctx.c = None
         return (None,) * 8 + out

@@ -8,89 +8,17 @@
 //           shading backward;
 //   pass 2  reverse suffix scan:  dL/dalpha_k = T_k dL/dw_k - (sum_{j>k} w_j dL/dw_j) / (1 - alpha_k + 1e-10),
 //           then dL/dsigma_k = dL/dalpha_k . delta_k s (1 - alpha_k) and dL/df_k through the activation;
-//   pass 3  4 lanes per sample re-gather the plane/line values and scatter-add
-//           dL/dP = dL/df . (L m) m . w_tap,  dL/dL = dL/df . (P m) m . w_tap  with float atomics on the
-//           channel-last gradient tensors (64-B contiguous per 4-lane group and tap).
+//   pass 3  scatter  dL/dP = dL/df . (L m) m . w_tap,  dL/dL = dL/df . (P m) m . w_tap  with float atomics on
+//           the channel-last gradient tensors.  Global float atomics on random 64..128-B pieces run far
+//           below the streaming atomic rate (each piece is its own memory-side request), so the scatter is
+//           run-length merged: consecutive samples of the ray that share a footprint are summed in
+//           registers and leave as ONE atomic per lane (tf_device.h vm_chunk_*).  The small, heavily shared
+//           line tensors are additionally spread over replicas (TfFactorGrads.n_rep).
 #include "tf_device.h"
 
 using namespace tf;
 
 namespace {
-
-__device__ __forceinline__ void atomic_add4(float* p, const float4_t& v) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) atomicAdd(p + k, v[k]);
-}
-
-// scatter of one sample's density-feature gradient; lane `sub` of the 4-lane group covers channel quads
-// sub, sub+4, ...
-__device__ __forceinline__ void density_scatter(int model, const TfFactors& D, const TfFactorGrads& G,
-                                                const int grid[3], const float u[3], int sub, float df) {
-    if (model == TF_MODEL_VM) {
-        VmTaps t;
-        make_vm_taps(grid, u, t);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int C = D.n_comp[i];
-            const float* mk = D.mask[i];
-            float* gp = G.plane[i];
-            float* gl = G.line[i];
-            const Tap2& tp = t.p[i];
-            const Tap1& tl = t.l[i];
-            if ((C & 3) == 0) {
-                for (int q = sub; q < (C >> 2); q += 4) {
-                    const int ch = q * 4;
-                    float4_t p = bilerp4(D.plane[i], C, tp, ch);
-                    float4_t l = lerp4(D.line[i], C, tl, ch);
-                    float4_t m2 = {1.f, 1.f, 1.f, 1.f};
-                    if (mk) {
-                        float4_t m = ld4(mk + ch);
-                        m2 = m * m;                       // (P m)(L m): mask enters squared (tensoRF.py:225)
-                    }
-                    const float4_t gP = l * m2 * df, gL = p * m2 * df;
-                    if (tp.w00 != 0.f) atomic_add4(gp + (size_t)tp.o00 * C + ch, gP * tp.w00);
-                    if (tp.w01 != 0.f) atomic_add4(gp + (size_t)tp.o01 * C + ch, gP * tp.w01);
-                    if (tp.w10 != 0.f) atomic_add4(gp + (size_t)tp.o10 * C + ch, gP * tp.w10);
-                    if (tp.w11 != 0.f) atomic_add4(gp + (size_t)tp.o11 * C + ch, gP * tp.w11);
-                    if (tl.w0 != 0.f) atomic_add4(gl + (size_t)tl.o0 * C + ch, gL * tl.w0);
-                    if (tl.w1 != 0.f) atomic_add4(gl + (size_t)tl.o1 * C + ch, gL * tl.w1);
-                }
-            } else {
-                for (int c = sub; c < C; c += 4) {
-                    const float p = bilerp1(D.plane[i], C, tp, c), l = lerp1(D.line[i], C, tl, c);
-                    const float m2 = mk ? mk[c] * mk[c] : 1.f;
-                    const float gP = l * m2 * df, gL = p * m2 * df;
-                    if (tp.w00 != 0.f) atomicAdd(gp + (size_t)tp.o00 * C + c, gP * tp.w00);
-                    if (tp.w01 != 0.f) atomicAdd(gp + (size_t)tp.o01 * C + c, gP * tp.w01);
-                    if (tp.w10 != 0.f) atomicAdd(gp + (size_t)tp.o10 * C + c, gP * tp.w10);
-                    if (tp.w11 != 0.f) atomicAdd(gp + (size_t)tp.o11 * C + c, gP * tp.w11);
-                    if (tl.w0 != 0.f) atomicAdd(gl + (size_t)tl.o0 * C + c, gL * tl.w0);
-                    if (tl.w1 != 0.f) atomicAdd(gl + (size_t)tl.o1 * C + c, gL * tl.w1);
-                }
-            }
-        }
-    } else {
-        // CP: f = sum_c L0 L1 L2 m  (tensoRF.py:363-384)
-        const int C = D.n_comp[0];
-        Tap1 t[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) t[i] = make_tap1(u[vecm(i)], grid[vecm(i)]);
-        const float* mk = D.mask[0];
-        for (int c = sub; c < C; c += 4) {
-            float l[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) l[i] = lerp1(D.line[i], C, t[i], c);
-            const float m = mk ? mk[c] : 1.f;
-            const float g0 = l[1] * l[2] * m * df, g1 = l[0] * l[2] * m * df, g2 = l[0] * l[1] * m * df;
-            const float g[3] = {g0, g1, g2};
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                if (t[i].w0 != 0.f) atomicAdd(G.line[i] + (size_t)t[i].o0 * C + c, g[i] * t[i].w0);
-                if (t[i].w1 != 0.f) atomicAdd(G.line[i] + (size_t)t[i].o1 * C + c, g[i] * t[i].w1);
-            }
-        }
-    }
-}
 
 struct BwdArgs {
     const float* grad_rgb_map;   // (R,3) dL/d rgb_map (after clamp)
@@ -220,19 +148,56 @@ __global__ __launch_bounds__(64) void march_backward_kernel(const TfField F, con
     }
     __syncthreads();
 
-    // ---------------- pass 3: scatter, 4 lanes per sample
-    for (int kb = 0; kb < cnt; kb += 16) {
-        const int slot = kb + (lane >> 2);
-        if (slot < cnt) {
-            const float df = sd[slot];
-            if (df != 0.f) {
-                const int idx = io.val_idx[vbase + slot];
-                float p[3], u[3];
-                sample_pos(ray, sample_z(F, ray, ztab, idx), p);
+    // ---------------- pass 3: scatter
+    if (F.model == TF_MODEL_VM) {
+        // run-length merged scatter over chunks of 16 consecutive valid samples (tf_device.h)
+        float* cbuf = smem + 3 * ncap;
+        const int ctot = F.density.n_comp[0] + F.density.n_comp[1] + F.density.n_comp[2];
+        for (int kb = 0; kb < cnt; kb += kChunk) {
+            const int ns = min(kChunk, cnt - kb);
+            auto u_of = [&](int s_, float* u) {
+                float p[3];
+                sample_pos(ray, sample_z(F, ray, ztab, io.val_idx[vbase + kb + s_]), p);
                 normalize(F, p, u);
-                density_scatter(F.model, F.density, G, F.grid, u, lane & 3, df);
-            }
+            };
+            vm_chunk_gather(F.density, F.grid, ctot, ns, u_of, cbuf, lane);
+            __syncthreads();
+            auto dprod = [&](int s_, int) { return sd[kb + s_]; };
+            vm_chunk_merge_scatter(F.density, G, F.grid, ctot, ns, dprod, cbuf, lane);
+            __syncthreads();
         }
+        return;
+    }
+    // CP: the whole wave on two samples at a time; the gather of the next pair is issued before the atomics
+    // of the current one
+    const int nit = pair_iters(F.model, F.density);
+    PairVals cur, nxt;
+    bool have = false;
+    for (int kb = 0; kb < cnt; kb += 2) {
+        const float dfA = sd[kb], dfB = kb + 1 < cnt ? sd[kb + 1] : 0.f;
+        if (dfA == 0.f && dfB == 0.f) continue;
+        float uA[3], uB[3], p[3];
+        sample_pos(ray, sample_z(F, ray, ztab, io.val_idx[vbase + kb]), p);
+        normalize(F, p, uA);
+        sample_pos(ray, sample_z(F, ray, ztab, io.val_idx[vbase + (kb + 1 < cnt ? kb + 1 : kb)]), p);
+        normalize(F, p, uB);
+        auto dprod = [&](int s, int, int) { return s ? dfB : dfA; };
+        for (int it = 0; it < nit; ++it) {
+            cp_pair_gather(F.density, G, F.grid, uA, uB, dfA != 0.f, dfB != 0.f, dprod, lane, it, nxt);
+            if (have) pair_commit(cur);
+            cur = nxt;
+            have = true;
+        }
+    }
+    if (have) pair_commit(cur);
+}
+
+__global__ __launch_bounds__(256) void reduce_replicas_kernel(const float* __restrict__ rep, int n_rep, int stride,
+                                                              int numel, float* __restrict__ dst) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < numel; j += gridDim.x * blockDim.x) {
+        float a = 0.f;
+        for (int r = 0; r < n_rep; ++r) a += rep[(size_t)r * stride + j];
+        dst[j] = a;
     }
 }
 
@@ -240,13 +205,22 @@ __global__ __launch_bounds__(64) void march_backward_kernel(const TfField F, con
 
 extern "C" {
 
+int tf_reduce_replicas(const float* rep, int n_rep, int stride, int numel, float* dst, tf_stream_t stream) {
+    if (numel <= 0) return 0;
+    hipLaunchKernelGGL(reduce_replicas_kernel, dim3((numel + 255) / 256), dim3(256), 0, (hipStream_t)stream, rep, n_rep,
+                       stride, numel, dst);
+    return TF_CHECK_LAUNCH();
+}
+
 int tf_march_backward(const TfField* field, const TfMarchIO* io, const float* grad_rgb_map, const float* rgb_pre,
                       int white_bg, const float* rgb, float* grad_rgb, const TfFactorGrads* dgrads,
                       tf_stream_t stream) {
     if (io->n_rays <= 0) return 0;
     if (io->n_samples <= 0 || io->n_samples > TF_MAX_SAMPLES) return (int)hipErrorInvalidValue;
     const int ncap = (io->n_samples + 63) & ~63;
-    const size_t lds = (size_t)ncap * 12;
+    const int ctot = field->density.n_comp[0] + field->density.n_comp[1] + field->density.n_comp[2];
+    const size_t lds = (size_t)ncap * 12 + (field->model == TF_MODEL_VM ? (size_t)chunk_lds_words(ctot) * 4 : 0);
+    if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
     BwdArgs B{grad_rgb_map, rgb_pre, rgb, grad_rgb, white_bg};
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(march_backward_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -255,5 +229,11 @@ int tf_march_backward(const TfField* field, const TfMarchIO* io, const float* gr
                        *dgrads);
     return TF_CHECK_LAUNCH();
 }
+
+#ifdef TF_PHASE_TIMING
+int tf_debug_set_flags_march(int flags) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(tf_dbg_flags), &flags, sizeof(int));
+}
+#endif
 
 }  // extern "C"

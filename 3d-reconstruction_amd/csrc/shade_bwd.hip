@@ -62,82 +62,6 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[NA][NBT]) {
         for (int j = 0; j < NBT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
-__device__ __forceinline__ void atomic_add4(float* p, const float4_t& v) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) atomicAdd(p + k, v[k]);
-}
-
-// scatter of one sample's appearance-product gradient dv[0..n_app) (LDS row); lane `sub` covers channel quads
-// sub, sub+4, ... exactly like app_products().
-__device__ __forceinline__ void app_scatter(const TfShade& S, const TfFactorGrads& G, const float u[3], int sub,
-                                            const float* dv) {
-    if (S.model == TF_MODEL_VM) {
-        VmTaps t;
-        make_vm_taps(S.grid, u, t);
-        int coff = 0;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int C = S.app.n_comp[i];
-            const float* mk = S.app.mask[i];
-            float* gp = G.plane[i];
-            float* gl = G.line[i];
-            const Tap2& tp = t.p[i];
-            const Tap1& tl = t.l[i];
-            if ((C & 3) == 0 && (coff & 3) == 0) {
-                for (int q = sub; q < (C >> 2); q += 4) {
-                    const int ch = q * 4;
-                    const float4_t p = bilerp4(S.app.plane[i], C, tp, ch);
-                    const float4_t l = lerp4(S.app.line[i], C, tl, ch);
-                    float4_t d = *reinterpret_cast<const float4_t*>(dv + coff + ch);
-                    if (mk) {
-                        const float4_t m = ld4(mk + ch);
-                        d *= m * m;
-                    }
-                    const float4_t gP = d * l, gL = d * p;
-                    if (tp.w00 != 0.f) atomic_add4(gp + (size_t)tp.o00 * C + ch, gP * tp.w00);
-                    if (tp.w01 != 0.f) atomic_add4(gp + (size_t)tp.o01 * C + ch, gP * tp.w01);
-                    if (tp.w10 != 0.f) atomic_add4(gp + (size_t)tp.o10 * C + ch, gP * tp.w10);
-                    if (tp.w11 != 0.f) atomic_add4(gp + (size_t)tp.o11 * C + ch, gP * tp.w11);
-                    if (tl.w0 != 0.f) atomic_add4(gl + (size_t)tl.o0 * C + ch, gL * tl.w0);
-                    if (tl.w1 != 0.f) atomic_add4(gl + (size_t)tl.o1 * C + ch, gL * tl.w1);
-                }
-            } else {
-                for (int c = sub; c < C; c += 4) {
-                    const float p = bilerp1(S.app.plane[i], C, tp, c), l = lerp1(S.app.line[i], C, tl, c);
-                    float d = dv[coff + c];
-                    if (mk) d *= mk[c] * mk[c];
-                    const float gP = d * l, gL = d * p;
-                    if (tp.w00 != 0.f) atomicAdd(gp + (size_t)tp.o00 * C + c, gP * tp.w00);
-                    if (tp.w01 != 0.f) atomicAdd(gp + (size_t)tp.o01 * C + c, gP * tp.w01);
-                    if (tp.w10 != 0.f) atomicAdd(gp + (size_t)tp.o10 * C + c, gP * tp.w10);
-                    if (tp.w11 != 0.f) atomicAdd(gp + (size_t)tp.o11 * C + c, gP * tp.w11);
-                    if (tl.w0 != 0.f) atomicAdd(gl + (size_t)tl.o0 * C + c, gL * tl.w0);
-                    if (tl.w1 != 0.f) atomicAdd(gl + (size_t)tl.o1 * C + c, gL * tl.w1);
-                }
-            }
-            coff += C;
-        }
-    } else {
-        const int C = S.app.n_comp[0];
-        Tap1 t[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) t[i] = make_tap1(u[vecm(i)], S.grid[vecm(i)]);
-        const float* mk = S.app.mask[0];
-        for (int c = sub; c < C; c += 4) {
-            float l[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) l[i] = lerp1(S.app.line[i], C, t[i], c);
-            const float d = dv[c] * (mk ? mk[c] : 1.f);
-            const float g[3] = {d * l[1] * l[2], d * l[0] * l[2], d * l[0] * l[1]};
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                if (t[i].w0 != 0.f) atomicAdd(G.line[i] + (size_t)t[i].o0 * C + c, g[i] * t[i].w0);
-                if (t[i].w1 != 0.f) atomicAdd(G.line[i] + (size_t)t[i].o1 * C + c, g[i] * t[i].w1);
-            }
-        }
-    }
-}
-
 struct BwdLds {
     int sv, sx, sh, sf;
     int offV, offX, offH1, offH2, offDo, offInfo, offPre, total;
@@ -199,6 +123,7 @@ __global__ __launch_bounds__(256, 1) void shade_backward_kernel(const TfShade S,
         __syncthreads();
     }
 
+    TF_T0();
     for (int t = blockIdx.x;; t += gridDim.x) {
         int s0, n;
         if (!locate_tile(src, pre, t, s0, n)) break;
@@ -352,6 +277,7 @@ __global__ __launch_bounds__(256, 1) void shade_backward_kernel(const TfShade S,
             }
         }
         __syncthreads();
+        TF_MARK(0);
 
         // ================= backward =================
         {   // per-feature pass: dW3, db3, dZ2 (in place of H2), db2.  2 threads per feature (sample halves)
@@ -376,9 +302,11 @@ __global__ __launch_bounds__(256, 1) void shade_backward_kernel(const TfShade S,
             }
         }
         __syncthreads();
+        TF_MARK(1);
         // dW2[f2][f1] += sum_s dZ2[s][f2] H1[s][f1]
         mma_gen<NF, FT, COL, COL>(H2, L.sh, 16 * NF * wave, H1, L.sh, 0, M / 16, aW2);
         __syncthreads();   // every wave is done reading H1 for dW2
+        TF_MARK(2);
         {   // dH1[f1][s] = sum_f2 W2[f2][f1] dZ2[s][f2];  dZ1 = dH1 . [H1 > 0] written in place of H1
             f32x4 acc[NF][4];
             zero_acc(acc);
@@ -399,6 +327,7 @@ __global__ __launch_bounds__(256, 1) void shade_backward_kernel(const TfShade S,
             }
         }
         __syncthreads();
+        TF_MARK(3);
         {   // db1 += column sums of dZ1
             const int f = tid % FC, half = tid / FC;
             if (half < 2 && FC <= 128) {
@@ -420,6 +349,7 @@ __global__ __launch_bounds__(256, 1) void shade_backward_kernel(const TfShade S,
             }
         }
         __syncthreads();   // dW1 finished reading X; the H2 region (dZ2) is free
+        TF_MARK(4);
         for (int it = tid; it < M * S.app_dim; it += 256) {   // feat copy for the PE derivative
             const int smp = it / S.app_dim, d = it % S.app_dim;
             Fs[smp * L.sf + d] = X[smp * L.sx + d];
@@ -436,6 +366,7 @@ __global__ __launch_bounds__(256, 1) void shade_backward_kernel(const TfShade S,
                 *reinterpret_cast<f32x4*>(X + (16 * j + c) * L.sx + 16 * kt + 4 * g) = acc[0][j];
         }
         __syncthreads();
+        TF_MARK(5);
         {   // dfeat = dX[:, :D] + PE'(feat): d/dx [sin(x 2^k) m_s] = cos(.) 2^k m_s,  d/dx [cos(.) m_c] = -sin(.) 2^k m_c
             for (int it = tid; it < M * 16 * NB; it += 256) {
                 const int smp = it / (16 * NB), d = it % (16 * NB);
@@ -493,15 +424,51 @@ __global__ __launch_bounds__(256, 1) void shade_backward_kernel(const TfShade S,
                 *reinterpret_cast<f32x4*>(V + (16 * j + c) * L.sv + 16 * ct + 4 * g) = acc[0][j];
         }
         __syncthreads();
-        {   // scatter-add into the appearance factor gradients
-            const int smp = wave * 16 + (lane >> 2), sub = lane & 3;
-            if (smp < n) {
-                float u[3] = {ixyz[smp * 3], ixyz[smp * 3 + 1], ixyz[smp * 3 + 2]};
-                app_scatter(S, G.app, u, sub, V + smp * L.sv);
+        TF_MARK(6);
+        // scatter-add into the appearance factor gradients
+        if (S.model == TF_MODEL_VM) {
+            // run-length merged scatter (tf_device.h): each wave takes its 16 samples as one chunk; the X and
+            // H1 regions are free by now and hold the per-wave chunk buffers
+            const int ctot = S.n_app_total;
+            float* cbuf = X + wave * chunk_lds_words(ctot);
+            const int ns = min(kChunk, n - wave * 16);
+            if (ns > 0) {
+                auto u_of = [&](int s_, float* u) {
+                    const int smp = wave * 16 + s_;
+                    u[0] = ixyz[smp * 3]; u[1] = ixyz[smp * 3 + 1]; u[2] = ixyz[smp * 3 + 2];
+                };
+                vm_chunk_gather(S.app, S.grid, ctot, ns, u_of, cbuf, lane);
             }
+            __syncthreads();
+            if (ns > 0) {
+                auto dprod = [&](int s_, int c) { return V[(wave * 16 + s_) * L.sv + c]; };
+                vm_chunk_merge_scatter(S.app, G.app, S.grid, ctot, ns, dprod, cbuf, lane);
+            }
+        } else {
+            const int nit = pair_iters(S.model, S.app);
+            PairVals cur, nxt;
+            bool have = false;
+            for (int pr = 0; pr < 8; ++pr) {
+                const int sA = wave * 16 + 2 * pr, sB = sA + 1;
+                if (sA >= n) break;
+                const float uA[3] = {ixyz[sA * 3], ixyz[sA * 3 + 1], ixyz[sA * 3 + 2]};
+                const float uB[3] = {ixyz[sB * 3], ixyz[sB * 3 + 1], ixyz[sB * 3 + 2]};
+                const float* dvA = V + sA * L.sv;
+                const float* dvB = V + sB * L.sv;
+                auto dprod = [&](int s, int, int c) { return (s ? dvB : dvA)[c]; };
+                for (int it = 0; it < nit; ++it) {
+                    cp_pair_gather(S.app, G.app, S.grid, uA, uB, true, sB < n, dprod, lane, it, nxt);
+                    if (have) pair_commit(cur);
+                    cur = nxt;
+                    have = true;
+                }
+            }
+            if (have) pair_commit(cur);
         }
         __syncthreads();
+        TF_MARK(7);
     }
+    TF_FLUSH();
 
     // ================= flush the workgroup's weight gradients =================
     {
@@ -573,11 +540,27 @@ int tf_shade_backward(const TfShade* shade, const float* rays, int ndc, const in
     const BwdLds L = bwd_lds(*shade);
     const size_t bytes = (size_t)L.total * sizeof(float);
     if (bytes > 160 * 1024) return (int)hipErrorInvalidValue;
+    if (shade->model == TF_MODEL_VM && 4 * chunk_lds_words(shade->n_app_total) > M * (L.sx + 2 * L.sh))
+        return (int)hipErrorInvalidValue;   // scatter chunk buffers live in the X | H1 | H2 regions
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;
     TileSrc src{counters, seg_cap, 0, app_ray, app_xyz, rays, ndc};
     hipLaunchKernelGGL(fn, dim3(256), dim3(256), bytes, (hipStream_t)stream, *shade, src, grad_rgb, *grads);
     return TF_CHECK_LAUNCH();
 }
+
+#ifdef TF_PHASE_TIMING
+int tf_debug_set_flags_shade(int flags) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(tf_dbg_flags), &flags, sizeof(int));
+}
+int tf_debug_phase_cycles_bwd(unsigned long long* out16, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(tf_phase_cycles), sizeof(unsigned long long) * 16);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(tf_phase_cycles), z, sizeof(z));
+    }
+    return (int)e;
+}
+#endif
 
 }  // extern "C"

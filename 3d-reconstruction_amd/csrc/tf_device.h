@@ -6,12 +6,24 @@
 // multiply-add is wanted (feature accumulation), it is written explicitly as fmaf().
 #pragma once
 #include <hip/hip_runtime.h>
+#include <limits.h>
 #include <stdint.h>
 #include "../../include/tensorf_hip.h"
 
 #define TF_CHECK_LAUNCH() (int)hipGetLastError()
 
 namespace tf {
+
+// Diagnostic build only (-DTF_PHASE_TIMING): switches to ablate the atomic traffic (bit 0: skip plane
+// atomics, bit 1: skip line atomics).  Compiled out of the shipped library.
+#ifdef TF_PHASE_TIMING
+static __device__ int tf_dbg_flags;
+#define TF_SKIP_PLANE_ATOMICS (tf_dbg_flags & 1)
+#define TF_SKIP_LINE_ATOMICS (tf_dbg_flags & 2)
+#else
+#define TF_SKIP_PLANE_ATOMICS 0
+#define TF_SKIP_LINE_ATOMICS 0
+#endif
 
 typedef float float4_t __attribute__((ext_vector_type(4)));
 
@@ -297,6 +309,261 @@ __device__ __forceinline__ float density_partial(int model, const TfFactors& D, 
         }
     }
     return acc;
+}
+
+// ---- gradient scatter (backward of the VM / CP lookups) ---------------------------------------------
+// One whole wave scatters the factor gradients of up to TWO samples (A, B).  `dprod(s, i, ch)` returns
+// dL/d(product) of sample s (0 = A, 1 = B) for component ch of plane/line pair i; for the density field
+// that is dL/df, for the appearance field dL/dV[coff_i + ch].
+//
+// Lane -> (tap, channel) maps follow MEMORY order, so that each atomic wave-instruction covers 256
+// contiguous bytes or two 128-B segments in two rows (MI355X_MICROARCH 'Global float atomics'):
+//   plane i : footprint of one sample = 2 rows x (2 taps x C floats contiguous); j in [0,4C) -> row, tap, c
+//   line  i : footprint of one sample = 2 taps x C floats contiguous; two samples -> j in [0,4C)
+// The work is split into a GATHER step (all loads of a pair, values + destination addresses into
+// registers) and a COMMIT step (the atomics, back to back), so callers can issue the gather of the next
+// pair before committing the current one: loads never wait behind the atomics they do not depend on.
+// The line tensors are scattered into replica (blockIdx % n_rep).
+struct PairVals {
+    float v[9];    // [3i+0] plane i / sample A, [3i+1] plane i / sample B, [3i+2] line i (sample chosen per lane)
+    float* a[9];
+};
+
+template <class DP>
+__device__ __forceinline__ void vm_pair_gather(const TfFactors& F, const TfFactorGrads& G, const int grid[3],
+                                               const float uA[3], const float uB[3], bool hasA, bool hasB, DP dprod,
+                                               int lane, int it, PairVals& out) {
+    const size_t rep = (size_t)(blockIdx.x % G.n_rep) * G.rep_stride;
+    const int j = lane + 64 * it;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int C = F.n_comp[i], C2 = 2 * C, C4 = 4 * C;
+        const float* mk = F.mask[i];
+        out.v[3 * i] = out.v[3 * i + 1] = out.v[3 * i + 2] = 0.f;
+        out.a[3 * i] = out.a[3 * i + 1] = G.plane[i];
+        out.a[3 * i + 2] = G.line[i];
+        if (j >= C4) continue;
+        const int hi = j >= C2, o = j - (hi ? C2 : 0), tx = o >= C, c = o - (tx ? C : 0);
+        const float m2 = mk ? mk[c] * mk[c] : 1.f;                 // (P m)(L m): the mask enters squared
+        const Tap2 tpA = make_tap2(uA[mat0(i)], uA[mat1(i)], grid[mat0(i)], grid[mat1(i)]);
+        const Tap2 tpB = make_tap2(uB[mat0(i)], uB[mat1(i)], grid[mat0(i)], grid[mat1(i)]);
+        const Tap1 tlA = make_tap1(uA[vecm(i)], grid[vecm(i)]);
+        const Tap1 tlB = make_tap1(uB[vecm(i)], grid[vecm(i)]);
+        // plane gradient: hi = row of the 2x2 footprint
+        if (hasA) {
+            const int off = hi ? (tx ? tpA.o11 : tpA.o10) : (tx ? tpA.o01 : tpA.o00);
+            const float w = hi ? (tx ? tpA.w11 : tpA.w10) : (tx ? tpA.w01 : tpA.w00);
+            out.v[3 * i] = lerp1(F.line[i], C, tlA, c) * dprod(0, i, c) * (w * m2);
+            out.a[3 * i] = G.plane[i] + (size_t)off * C + c;
+        }
+        if (hasB) {
+            const int off = hi ? (tx ? tpB.o11 : tpB.o10) : (tx ? tpB.o01 : tpB.o00);
+            const float w = hi ? (tx ? tpB.w11 : tpB.w10) : (tx ? tpB.w01 : tpB.w00);
+            out.v[3 * i + 1] = lerp1(F.line[i], C, tlB, c) * dprod(1, i, c) * (w * m2);
+            out.a[3 * i + 1] = G.plane[i] + (size_t)off * C + c;
+        }
+        // line gradient: hi = which sample
+        if (hi ? hasB : hasA) {
+            const Tap2& tp = hi ? tpB : tpA;
+            const Tap1& tl = hi ? tlB : tlA;
+            out.v[3 * i + 2] = bilerp1(F.plane[i], C, tp, c) * dprod(hi, i, c) * ((tx ? tl.w1 : tl.w0) * m2);
+            out.a[3 * i + 2] = G.line[i] + rep + (size_t)(tx ? tl.o1 : tl.o0) * C + c;
+        }
+    }
+}
+
+// CP: f = sum_c L0 L1 L2 m; d/dL_i = prod_{j != i} L_j * m   (tensoRF.py:363-384, 394-415).  Only v[3i+2] is used.
+template <class DP>
+__device__ __forceinline__ void cp_pair_gather(const TfFactors& F, const TfFactorGrads& G, const int grid[3],
+                                               const float uA[3], const float uB[3], bool hasA, bool hasB, DP dprod,
+                                               int lane, int it, PairVals& out) {
+    const size_t rep = (size_t)(blockIdx.x % G.n_rep) * G.rep_stride;
+    const int C = F.n_comp[0], C2 = 2 * C, C4 = 4 * C;
+    const int j = lane + 64 * it;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        out.v[k] = 0.f;
+        out.a[k] = G.line[k / 3];
+    }
+    if (j >= C4) return;
+    const int hi = j >= C2, o = j - (hi ? C2 : 0), tx = o >= C, c = o - (tx ? C : 0);
+    if (!(hi ? hasB : hasA)) return;
+    const float* u = hi ? uB : uA;
+    Tap1 t[3];
+    float l[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        t[i] = make_tap1(u[vecm(i)], grid[vecm(i)]);
+        l[i] = lerp1(F.line[i], C, t[i], c);
+    }
+    const float d = dprod(hi, 0, c) * (F.mask[0] ? F.mask[0][c] : 1.f);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float others = i == 0 ? l[1] * l[2] : (i == 1 ? l[0] * l[2] : l[0] * l[1]);
+        out.v[3 * i + 2] = d * others * (tx ? t[i].w1 : t[i].w0);
+        out.a[3 * i + 2] = G.line[i] + rep + (size_t)(tx ? t[i].o1 : t[i].o0) * C + c;
+    }
+}
+
+__device__ __forceinline__ void pair_commit(const PairVals& p) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        if ((k % 3 == 2) ? TF_SKIP_LINE_ATOMICS : TF_SKIP_PLANE_ATOMICS) continue;
+        if (p.v[k] != 0.f) atomicAdd(p.a[k], p.v[k]);
+    }
+}
+
+// ---- run-length merged scatter (VM) ------------------------------------------------------------------
+// Consecutive samples of a ray are half a voxel apart, so they mostly share their 2x2 plane footprint and
+// their 2-tap line footprint.  The merged scatter therefore works on a CHUNK of up to 16 consecutive samples
+// of one wave in two steps:
+//   gather : 4 lanes per sample read the plane / line values (16-B pieces, like the forward) and park
+//            P m^2 and L m^2 plus the per-sample tap geometry in LDS;
+//   merge  : lanes are laid out in footprint MEMORY order (row, tap, channel); the wave walks the chunk's
+//            samples in order, accumulating in a register while the footprint base stays the same and
+//            issuing ONE atomic per lane when it changes (or the chunk ends).
+// On the benchmark scene this removes ~60 % of the plane atomics and ~75 % of the line atomics.
+struct TapMeta {      // geometry of one sample on plane/line pair i
+    int x0, y0;       // footprint base texel (bilinear floor)
+    float fx, fy;     // fractions; weights are (1-f, f) per axis
+    int l0;           // line base entry
+    float lf;
+};
+constexpr int kChunk = 16;
+
+// words of LDS one wave needs for a chunk with `ctot` components in total
+__host__ __device__ inline int chunk_lds_words(int ctot) { return kChunk * 3 * 6 + 2 * kChunk * ctot; }
+
+__device__ __forceinline__ void tap_floor(float u, int size, int& i0, float& f) {
+    float x = unnorm(u, size);
+    x = fminf(fmaxf(x, -2.f), (float)size + 1.f);
+    const float x0 = floorf(x);
+    f = x - x0;
+    i0 = (int)x0;
+}
+
+// Gather step.  `u_of(s, u)` fills the normalised coordinate of chunk sample s.  Layout in `buf`:
+// TapMeta meta[kChunk][3]; float Ps[kChunk][ctot]; float Ls[kChunk][ctot].
+template <class UF>
+__device__ __forceinline__ void vm_chunk_gather(const TfFactors& F, const int grid[3], int ctot, int ns, UF u_of,
+                                                float* buf, int lane) {
+    TapMeta* meta = reinterpret_cast<TapMeta*>(buf);
+    float* Ps = buf + kChunk * 3 * 6;
+    float* Ls = Ps + kChunk * ctot;
+    const int s = lane >> 2, sub = lane & 3;
+    if (s >= ns) return;
+    float u[3];
+    u_of(s, u);
+    VmTaps t;
+    make_vm_taps(grid, u, t);
+    int coff = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int C = F.n_comp[i];
+        const float* mk = F.mask[i];
+        if (sub == 0) {
+            TapMeta m;
+            tap_floor(u[mat0(i)], grid[mat0(i)], m.x0, m.fx);
+            tap_floor(u[mat1(i)], grid[mat1(i)], m.y0, m.fy);
+            tap_floor(u[vecm(i)], grid[vecm(i)], m.l0, m.lf);
+            meta[s * 3 + i] = m;
+        }
+        float* ps = Ps + s * ctot + coff;
+        float* ls = Ls + s * ctot + coff;
+        if ((C & 3) == 0 && (coff & 3) == 0 && (ctot & 3) == 0) {
+            for (int q = sub; q < (C >> 2); q += 4) {
+                float4_t p = bilerp4(F.plane[i], C, t.p[i], q * 4);
+                float4_t l = lerp4(F.line[i], C, t.l[i], q * 4);
+                if (mk) {
+                    const float4_t m = ld4(mk + q * 4);
+                    p *= m * m;                                  // (P m)(L m): the mask enters squared
+                    l *= m * m;
+                }
+                *reinterpret_cast<float4_t*>(ps + q * 4) = p;
+                *reinterpret_cast<float4_t*>(ls + q * 4) = l;
+            }
+        } else {
+            for (int c = sub; c < C; c += 4) {
+                const float m2 = mk ? mk[c] * mk[c] : 1.f;
+                ps[c] = bilerp1(F.plane[i], C, t.p[i], c) * m2;
+                ls[c] = lerp1(F.line[i], C, t.l[i], c) * m2;
+            }
+        }
+        coff += C;
+    }
+}
+
+// Merge + scatter step.  `dprod(s, coff_i + c)` = dL/d(product) of chunk sample s, component coff_i + c.
+template <class DP>
+__device__ __forceinline__ void vm_chunk_merge_scatter(const TfFactors& F, const TfFactorGrads& G, const int grid[3],
+                                                       int ctot, int ns, DP dprod, const float* buf, int lane) {
+    const TapMeta* meta = reinterpret_cast<const TapMeta*>(buf);
+    const float* Ps = buf + kChunk * 3 * 6;
+    const float* Ls = Ps + kChunk * ctot;
+    const size_t rep = (size_t)(blockIdx.x % G.n_rep) * G.rep_stride;
+    int coff = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int C = F.n_comp[i], W = grid[mat0(i)], Hh = grid[mat1(i)], Gl = grid[vecm(i)];
+        // ---------- plane gradient: j -> (row, tap, channel) in memory order
+        if (!TF_SKIP_PLANE_ATOMICS) {
+            for (int j0 = 0; j0 < 4 * C; j0 += 64) {
+                const int j = j0 + lane;
+                const bool on = j < 4 * C;
+                const int row = j >= 2 * C, o = j - (row ? 2 * C : 0), tx = o >= C, c = o - (tx ? C : 0);
+                float acc = 0.f;
+                int kx = INT_MIN, ky = INT_MIN;
+                float* gp = G.plane[i];
+                for (int s = 0; s < ns; ++s) {
+                    const TapMeta& m = meta[s * 3 + i];
+                    if (m.x0 != kx || m.y0 != ky) {                    // wave-uniform: new footprint
+                        if (on && acc != 0.f) atomicAdd(gp + ((size_t)(ky + row) * W + (kx + tx)) * C + c, acc);
+                        acc = 0.f;
+                        kx = m.x0;
+                        ky = m.y0;
+                    }
+                    const bool ok = on && (unsigned)(kx + tx) < (unsigned)W && (unsigned)(ky + row) < (unsigned)Hh;
+                    if (ok) {
+                        const float w = (row ? m.fy : 1.f - m.fy) * (tx ? m.fx : 1.f - m.fx);
+                        acc = fmaf(dprod(s, coff + c) * Ls[s * ctot + coff + c], w, acc);
+                    }
+                }
+                if (on && acc != 0.f) atomicAdd(gp + ((size_t)(ky + row) * W + (kx + tx)) * C + c, acc);
+            }
+        }
+        // ---------- line gradient: j -> (tap, channel)
+        if (!TF_SKIP_LINE_ATOMICS) {
+            for (int j0 = 0; j0 < 2 * C; j0 += 64) {
+                const int j = j0 + lane;
+                const bool on = j < 2 * C;
+                const int tx = j >= C, c = j - (tx ? C : 0);
+                float acc = 0.f;
+                int kl = INT_MIN;
+                float* gl = G.line[i] + rep;
+                for (int s = 0; s < ns; ++s) {
+                    const TapMeta& m = meta[s * 3 + i];
+                    if (m.l0 != kl) {
+                        if (on && acc != 0.f) atomicAdd(gl + (size_t)(kl + tx) * C + c, acc);
+                        acc = 0.f;
+                        kl = m.l0;
+                    }
+                    if (on && (unsigned)(kl + tx) < (unsigned)Gl) {
+                        const float w = tx ? m.lf : 1.f - m.lf;
+                        acc = fmaf(dprod(s, coff + c) * Ps[s * ctot + coff + c], w, acc);
+                    }
+                }
+                if (on && acc != 0.f) atomicAdd(gl + (size_t)(kl + tx) * C + c, acc);
+            }
+        }
+        coff += C;
+    }
+}
+
+// number of 64-lane iterations a pair needs
+__device__ __forceinline__ int pair_iters(int model, const TfFactors& F) {
+    int c = F.n_comp[0];
+    if (model == TF_MODEL_VM) c = max(c, max(F.n_comp[1], F.n_comp[2]));
+    return (4 * c + 63) >> 6;
 }
 
 // feature2density (tensorBase.py:291-295); F.softplus = x > 20 ? x : log1p(exp(x))

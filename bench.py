@@ -59,8 +59,13 @@ def build_scene(recon, dev, grid, views, seed=0):
     rays = S.blender_rays(views)
     keep = S.bbox_hit_mask(rays, aabb.cpu())                          # filtering_rays(bbox_only=True), train.py:291
     rays = rays[keep].to(dev)
+    # targets: the field's own rendering plus zero-mean noise, so the gradients are non-trivial while the
+    # 'trained-like' state (and with it the per-ray sample counts of the workload) stays put over the run
+    with torch.no_grad():
+        teacher = recon.OctreeRender_trilinear_fast(rays, model, None, chunk=4096, N_samples=n_samples, white_bg=True,
+                                                    device=dev)[0]
     g = torch.Generator().manual_seed(seed + 1)
-    targets = torch.rand(rays.shape[0], 3, generator=g).to(dev)
+    targets = (teacher + 0.1 * torch.randn(rays.shape[0], 3, generator=g).to(dev)).clamp(0, 1)
     return model, rays, targets, n_samples, reso
 
 
@@ -152,7 +157,9 @@ def main():
         perm = perm.repeat((need + perm.numel() - 1) // perm.numel())
     perm = perm[:need].view(n_steps, B * world).to(dev)
 
-    opt = torch.optim.Adam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+    # train.py:272-273 (same optimizer, same groups / learning rates); fused=True only changes how torch
+    # batches the elementwise update
+    opt = torch.optim.Adam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), fused=True)
     renderer = recon_amd.OctreeRender_trilinear_fast
 
     def train_step(i):

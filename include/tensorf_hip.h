@@ -53,10 +53,15 @@ typedef struct TfFactors {
     int n_comp[3];
 } TfFactors;
 
-/* Gradient destinations, same layouts as TfFactors (accumulated with float atomics). */
+/* Gradient destinations, same layouts as TfFactors (accumulated with float atomics).  Line tensors are
+ * tiny (G x C) and every ray hits them, so their atomics are spread over `n_rep` replicas
+ * (replica r of line i at line[i] + r*rep_stride floats, workgroup b uses replica b % n_rep); the caller
+ * sums the replicas afterwards with tf_reduce_replicas. */
 typedef struct TfFactorGrads {
     float* plane[3];
     float* line[3];
+    int n_rep;        /* >= 1 */
+    int rep_stride;   /* floats between consecutive replicas */
 } TfFactorGrads;
 
 /* Geometry + density field + alpha mask: everything TensorBase.forward reads before shading.
@@ -184,6 +189,9 @@ typedef struct TfShadeGrads {
 int tf_shade_backward(const TfShade* shade, const float* rays, int ndc, const int* counters, int seg_cap,
                       const int* app_ray, const float* app_xyz, const float* grad_rgb, const TfShadeGrads* grads,
                       tf_stream_t stream);
+
+/* dst[j] = sum_r rep[r*stride + j], j < numel: folds the line-gradient replicas. */
+int tf_reduce_replicas(const float* rep, int n_rep, int stride, int numel, float* dst, tf_stream_t stream);
 
 /* Library identification: returns the gfx target string the kernels were compiled for. */
 const char* tf_build_info(void);
