@@ -336,16 +336,27 @@ __global__ __launch_bounds__(256, 1) void shade_backward_kernel(const TfShade S,
                 ab1 += a;
             }
         }
-        // dW1[f][k] += sum_s dZ1[s][f] X[s][k]
+        // dW1[f][k] += sum_s dZ1[s][f] X[s][k]: dZ1 fragments are read once per k-group and reused for every
+        // k tile of X
+        {
+            const int r = lane & 15, kq = lane >> 4;
+#pragma unroll 1
+            for (int kg = 0; kg < M / 16; ++kg) {
+                const int ks = 16 * kg + 4 * kq;
+                f32x4 a[NF];
 #pragma unroll
-        for (int j = 0; j < KT1; ++j) {
-            if (j < kt1) {
-                f32x4 one[NF][1];
+                for (int i = 0; i < NF; ++i) a[i] = ldfrag<COL>(H1, L.sh, 16 * (NF * wave + i) + r, ks);
 #pragma unroll
-                for (int i = 0; i < NF; ++i) one[i][0] = aW1[i][j];
-                mma_gen<NF, 1, COL, COL>(H1, L.sh, 16 * NF * wave, X, L.sx, 16 * j, M / 16, one);
+                for (int j = 0; j < KT1; ++j) {
+                    if (j < kt1) {
+                        const f32x4 b = ldfrag<COL>(X, L.sx, 16 * j + r, ks);
 #pragma unroll
-                for (int i = 0; i < NF; ++i) aW1[i][j] = one[i][0];
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int i = 0; i < NF; ++i)
+                                aW1[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[e], aW1[i][j], 0, 0, 0);
+                    }
+                }
             }
         }
         __syncthreads();   // dW1 finished reading X; the H2 region (dZ2) is free

@@ -443,8 +443,10 @@ class TensorBase(nn.Module):
                 return None, None
             j = self._jitter_override
             if j is None:
-                j = torch.rand(R, 1)
-            return j.reshape(-1).to(device=rays.device, dtype=torch.float32).contiguous(), None
+                # same CPU-generator draw as the reference, generated straight into pinned memory so the upload
+                # is asynchronous (a pageable H2D copy would drain the stream every training step)
+                j = torch.rand(R, 1, pin_memory=rays.is_cuda)
+            return j.reshape(-1).to(device=rays.device, dtype=torch.float32, non_blocking=True).contiguous(), None
         near, far = float(self.near_far[0]), float(self.near_far[1])
         key = (near, far, N, str(rays.device))
         base = self._ztab_cache.get(key)

@@ -2,6 +2,43 @@
 import torch
 
 
+class LazySampleCount:
+    """Deferred `num_samples` (6th return value).  The reference converts the per-chunk count with
+    `float(num_valid_samples)` (renderer.py:24), a device sync per chunk that stalls the launch pipeline; no
+    caller in the reference uses the value for control flow (train.py:323 ignores it).  When the model sets
+    `lazy_sample_count = True` the renderer returns this object instead: it behaves like the float in
+    `float()`, arithmetic, comparisons and formatting, and syncs only when first read."""
+
+    def __init__(self, tensors):
+        self._t, self._v = tensors, None
+
+    def __float__(self):
+        if self._v is None:
+            self._v = float(torch.stack([c.reshape(()) for c in self._t]).sum()) if self._t else 0.0
+            self._t = None
+        return self._v
+
+    def __int__(self):
+        return int(float(self))
+
+    def __add__(self, o):
+        return float(self) + float(o)
+
+    __radd__ = __add__
+
+    def __eq__(self, o):
+        return float(self) == float(o)
+
+    def __lt__(self, o):
+        return float(self) < float(o)
+
+    def __format__(self, spec):
+        return format(float(self), spec)
+
+    def __repr__(self):
+        return repr(float(self))
+
+
 def OctreeRender_trilinear_fast(rays, tensorf, mask=None, chunk=4096, N_samples=-1, ndc_ray=False, white_bg=True,
                                 is_train=False, device='cuda'):
     """Returns `(rgbs, None, depth_maps, None, None, num_samples: float)` like renderer.py:26.
@@ -25,5 +62,7 @@ def OctreeRender_trilinear_fast(rays, tensorf, mask=None, chunk=4096, N_samples=
         counts.append(num_valid_samples)
     if not rgbs:
         return torch.empty(0, 3), None, torch.empty(0), None, None, 0.0
-    total = float(torch.stack([c.reshape(()) for c in counts]).sum())
+    total = LazySampleCount(counts)
+    if not getattr(tensorf, 'lazy_sample_count', False):
+        total = float(total)
     return torch.cat(rgbs), None, torch.cat(depth_maps), None, None, total

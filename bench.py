@@ -160,6 +160,7 @@ def main():
     # train.py:272-273 (same optimizer, same groups / learning rates); fused=True only changes how torch
     # batches the elementwise update
     opt = torch.optim.Adam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), fused=True)
+    model.lazy_sample_count = True   # the renderer's 6th return value syncs only when read (train.py never reads it)
     renderer = recon_amd.OctreeRender_trilinear_fast
 
     def train_step(i):
@@ -236,7 +237,7 @@ def main():
                        "mode": args.mode, "batch_per_gpu": B, "global_batch": B * world, "n_samples": n_samples,
                        "per_ray": {"in_bbox": stats["bbox"] / B, "density": stats["density"] / B,
                                    "shaded": stats["shaded"] / B},
-                       "parallelism": f"ray-sharded dp{world}"},
+                       "parallelism": f"ray-sharded dp{world}", "lazy_sample_count": True},
             "roofline": roof,
             "kernels": {n: {"avg_ms": round(v["avg_ms"], 5), "GBps": round(v["GBps"], 1),
                             "TFLOPps": round(v["TFLOPps"], 2)} for n, v in kt.items()},
