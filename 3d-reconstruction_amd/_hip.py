@@ -63,7 +63,15 @@ class TfShade(C.Structure):
 
 class TfShadeGrads(C.Structure):
     _fields_ = [("w1", _fp), ("b1", _fp), ("w2", _fp), ("b2", _fp), ("w3", _fp), ("b3", _fp),
-                ("basis", _fp), ("app", TfFactorGrads)]
+                ("basis", _fp), ("app", TfFactorGrads), ("dv_out", _fp)]
+
+
+class TfBinJob(C.Structure):
+    _fields_ = [("factors", TfFactors), ("grads", TfFactorGrads), ("grid", C.c_int * 3), ("counters", _fp),
+                ("slot", C.c_int), ("seg_cap", C.c_int), ("xyz", _fp), ("grad", _fp), ("grad_ld", C.c_int),
+                ("tile", C.c_int), ("bucket", C.c_int), ("chunk", C.c_int),
+                ("hist", _fp), ("offsets", _fp), ("cursor", _fp), ("chunk_off", _fp), ("binned", _fp),
+                ("nkeys", C.c_int)]
 
 
 class HipError(RuntimeError):
@@ -82,7 +90,9 @@ _SIGS = {
     "tf_appfeature_points": [C.POINTER(TfShade), _fp, C.c_int, _fp, _fp],
     "tf_reduce_replicas": [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp],
     "tf_march_backward": [C.POINTER(TfField), C.POINTER(TfMarchIO), _fp, _fp, C.c_int, _fp, _fp,
-                          C.POINTER(TfFactorGrads), _fp],
+                          C.POINTER(TfFactorGrads), _fp, _fp, _fp],
+    "tf_bin_nkeys": [C.POINTER(C.c_int * 3), C.c_int, C.c_int],
+    "tf_binned_scatter": [C.POINTER(TfBinJob), _fp],
     "tf_shade_backward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp,
                           C.POINTER(TfShadeGrads), _fp],
 }

@@ -78,17 +78,39 @@ class _RenderFn(torch.autograd.Function):
                 if not cp:
                     fg.plane[i] = grads[f'{kind}_plane.{i}'].data_ptr()
                 fg.line[i] = rep0 + 4 * offs[f'{kind}_line.{i}']
+        binned = ws.binned_cfg is not None
+
+        def bin_job(factors, fgrads, slot, xyz, grad, grad_ld, part):
+            nkeys = ws.binned_cfg[0]
+            j = H.TfBinJob()
+            j.factors, j.grads = factors, fgrads
+            j.grid = c['field'].grid
+            j.counters, j.slot, j.seg_cap = ws.counters.data_ptr(), slot, ws.seg_cap
+            j.xyz, j.grad, j.grad_ld = xyz.data_ptr(), grad.data_ptr(), grad_ld
+            j.tile, j.bucket, j.chunk = model.bin_tile, model.bin_bucket, model.bin_chunk
+            ints = ws.bin_ints.data_ptr()
+            j.hist, j.offsets = ints, ints + 4 * (nkeys + 8)
+            j.cursor, j.chunk_off = ints + 8 * (nkeys + 8), ints + 12 * (nkeys + 8)
+            j.binned, j.nkeys = ws.binned.data_ptr(), nkeys
+            model._timed("tf_binned_scatter_" + part, lib.tf_binned_scatter, C.byref(j), st)
+
         model._timed("tf_march_backward", lib.tf_march_backward, C.byref(c['field']), C.byref(c['io']), g.data_ptr(),
-                     ws.rgb_pre.data_ptr(), int(c['use_bg']), ws.rgb.data_ptr(), ws.grad_rgb.data_ptr(), C.byref(dg), st)
+                     ws.rgb_pre.data_ptr(), int(c['use_bg']), ws.rgb.data_ptr(), ws.grad_rgb.data_ptr(), C.byref(dg),
+                     ws.ent_xyz.data_ptr() if binned else None, ws.ent_df.data_ptr() if binned else None, st)
+        if binned:
+            bin_job(c['field'].density, dg, 3, ws.ent_xyz, ws.ent_df, 0, "density")
         sg = H.TfShadeGrads()
         sg.w1, sg.b1 = grads['renderModule.mlp.0.weight'].data_ptr(), grads['renderModule.mlp.0.bias'].data_ptr()
         sg.w2, sg.b2 = grads['renderModule.mlp.2.weight'].data_ptr(), grads['renderModule.mlp.2.bias'].data_ptr()
         sg.w3, sg.b3 = grads['renderModule.mlp.4.weight'].data_ptr(), grads['renderModule.mlp.4.bias'].data_ptr()
         sg.basis = grads['basis_mat.weight'].data_ptr()
         sg.app = ag
+        sg.dv_out = ws.dv.data_ptr() if binned else None
         model._timed("tf_shade_backward", lib.tf_shade_backward, C.byref(c['shade']), c['rays'].data_ptr(),
                      int(c['ndc']), ws.counters.data_ptr(), ws.seg_cap, ws.app_ray.data_ptr(), ws.app_xyz.data_ptr(),
                      ws.grad_rgb.data_ptr(), C.byref(sg), st)
+        if binned:
+            bin_job(c['shade'].app, ag, 0, ws.app_xyz, ws.dv, model._n_app_total(), "app")
         model._timed("tf_reduce_replicas", lib.tf_reduce_replicas, rep0, N_REP, line_len, line_len, flat.data_ptr(), st)
         out = tuple(grads[n] if p.requires_grad else None for n, p in named)
         ctx.c = None

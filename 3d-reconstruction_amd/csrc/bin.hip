@@ -1,0 +1,371 @@
+// bin.hip — binned ("owner computes") scatter of the VM factor gradients.   gfx950, wave64.
+//
+// Why: the backward of the plane x line lookups adds 4 x C floats per (sample, plane) and 2 x C per (sample,
+// line) into the gradient tensors.  Done with global float atomics this is request-bound — random 64..128-B
+// pieces reach only ~0.4 TB/s on MI355X whatever the lane shape (measured) — and it was 60 % of
+// the training step.  Here the samples are counting-sorted by destination first:
+//     key(sample, plane i) = T x T texel tile of the footprint base     key(sample, line i) = LB-entry bucket
+//   K1 count   : per-workgroup LDS histogram over the 6 keys of every entry, flushed with int atomics
+//   K2 scan    : one workgroup, exclusive prefix of the histogram (+ prefix of ceil(count/chunk) work items)
+//   K3 fill    : per-workgroup LDS histogram again, ONE reservation per non-empty key, LDS ranks -> binned[]
+//   K4 scatter : persistent workgroups; a work item = <= chunk entries of one key; accumulate in an LDS block
+//                ((T+1)^2 x C floats for a tile, (LB+1) x C for a bucket) with LDS float atomics, flush the
+//                block once with contiguous global atomics (rows of (T+1) x C floats).
+// Every sample's contribution is computed exactly as in the direct scatter (tf_device.h), only the
+// accumulation order changes.
+#include "tf_device.h"
+
+using namespace tf;
+
+namespace {
+
+struct KeyMap {
+    int T, LB;
+    int ntx[3];
+    int plane_base[3], line_base[3];
+    int nkeys;
+};
+
+__host__ __device__ inline KeyMap make_keymap(const int grid[3], int T, int LB) {
+    KeyMap K;
+    K.T = T;
+    K.LB = LB;
+    int run = 0;
+    for (int i = 0; i < 3; ++i) {
+        const int W = grid[i == 2 ? 1 : 0], H = grid[i == 0 ? 1 : 2];
+        K.ntx[i] = (W + T - 1) / T;
+        K.plane_base[i] = run;
+        run += K.ntx[i] * ((H + T - 1) / T);
+    }
+    for (int i = 0; i < 3; ++i) {
+        K.line_base[i] = run;
+        run += (grid[2 - i] + LB - 1) / LB;
+    }
+    K.nkeys = run;
+    return K;
+}
+
+struct SampleGeom {
+    int x0[3], y0[3], l0[3];
+    float fx[3], fy[3], lf[3];
+};
+
+__device__ __forceinline__ void sample_geom(const int grid[3], const float u[3], SampleGeom& g) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        tap_floor(u[mat0(i)], grid[mat0(i)], g.x0[i], g.fx[i]);
+        tap_floor(u[mat1(i)], grid[mat1(i)], g.y0[i], g.fy[i]);
+        tap_floor(u[vecm(i)], grid[vecm(i)], g.l0[i], g.lf[i]);
+    }
+}
+
+__device__ __forceinline__ void sample_keys(const KeyMap& K, const int grid[3], const SampleGeom& g, int keys[6]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int x = min(max(g.x0[i], 0), grid[mat0(i)] - 1), y = min(max(g.y0[i], 0), grid[mat1(i)] - 1);
+        const int l = min(max(g.l0[i], 0), grid[vecm(i)] - 1);
+        keys[i] = K.plane_base[i] + (y / K.T) * K.ntx[i] + x / K.T;
+        keys[3 + i] = K.line_base[i] + l / K.LB;
+    }
+}
+
+constexpr int kSlices = 8;   // workgroups per entry shard in the count / fill passes
+
+// entries of shard g handled by slice k: local = k*256 + tid, += kSlices*256
+__global__ __launch_bounds__(256) void bin_count_kernel(const TfBinJob J, const KeyMap K) {
+    extern __shared__ int lh[];
+    for (int i = threadIdx.x; i < K.nkeys; i += 256) lh[i] = 0;
+    __syncthreads();
+    const int g = blockIdx.x / kSlices, k = blockIdx.x % kSlices;
+    const int cnt = J.counters[g * TF_SHARD_STRIDE + J.slot];
+    for (int local = k * 256 + threadIdx.x; local < cnt; local += kSlices * 256) {
+        const size_t e = (size_t)g * J.seg_cap + local;
+        const float u[3] = {J.xyz[e * 3], J.xyz[e * 3 + 1], J.xyz[e * 3 + 2]};
+        SampleGeom sg;
+        sample_geom(J.grid, u, sg);
+        int keys[6];
+        sample_keys(K, J.grid, sg, keys);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) atomicAdd(&lh[keys[q]], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K.nkeys; i += 256)
+        if (lh[i]) atomicAdd(&J.hist[i], lh[i]);
+}
+
+// offsets[] = exclusive prefix of hist[], chunk_off[] = exclusive prefix of ceil(hist/chunk); cursor = offsets
+__global__ __launch_bounds__(1024) void bin_scan_kernel(const TfBinJob J, int nkeys) {
+    __shared__ int part[1024], part2[1024];
+    const int tid = threadIdx.x;
+    const int per = (nkeys + 1023) / 1024;
+    int s = 0, s2 = 0;
+    for (int i = tid * per; i < min(nkeys, (tid + 1) * per); ++i) {
+        s += J.hist[i];
+        s2 += (J.hist[i] + J.chunk - 1) / J.chunk;
+    }
+    part[tid] = s;
+    part2[tid] = s2;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int a = tid >= o ? part[tid - o] : 0, b = tid >= o ? part2[tid - o] : 0;
+        __syncthreads();
+        part[tid] += a;
+        part2[tid] += b;
+        __syncthreads();
+    }
+    int run = part[tid] - s, run2 = part2[tid] - s2;
+    for (int i = tid * per; i < min(nkeys, (tid + 1) * per); ++i) {
+        J.offsets[i] = run;
+        J.cursor[i] = run;
+        J.chunk_off[i] = run2;
+        run += J.hist[i];
+        run2 += (J.hist[i] + J.chunk - 1) / J.chunk;
+    }
+    if (tid == 1023) {
+        J.offsets[nkeys] = part[1023];
+        J.chunk_off[nkeys] = part2[1023];
+    }
+    // item table: work item -> key (chunk index = item - chunk_off[key]); lives behind chunk_off[]
+    int* items = J.chunk_off + nkeys + 1;
+    run2 = part2[tid] - s2;
+    for (int i = tid * per; i < min(nkeys, (tid + 1) * per); ++i) {
+        const int nc = (J.hist[i] + J.chunk - 1) / J.chunk;
+        for (int c = 0; c < nc; ++c) items[run2 + c] = i;
+        run2 += nc;
+    }
+}
+
+__global__ __launch_bounds__(256) void bin_fill_kernel(const TfBinJob J, const KeyMap K) {
+    extern __shared__ int lds[];
+    int* lh = lds;               // counts, then running ranks
+    int* lb = lds + K.nkeys;     // reserved base per key
+    for (int i = threadIdx.x; i < K.nkeys; i += 256) lh[i] = 0;
+    __syncthreads();
+    const int g = blockIdx.x / kSlices, k = blockIdx.x % kSlices;
+    const int cnt = J.counters[g * TF_SHARD_STRIDE + J.slot];
+    for (int local = k * 256 + threadIdx.x; local < cnt; local += kSlices * 256) {
+        const size_t e = (size_t)g * J.seg_cap + local;
+        const float u[3] = {J.xyz[e * 3], J.xyz[e * 3 + 1], J.xyz[e * 3 + 2]};
+        SampleGeom sg;
+        sample_geom(J.grid, u, sg);
+        int keys[6];
+        sample_keys(K, J.grid, sg, keys);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) atomicAdd(&lh[keys[q]], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K.nkeys; i += 256) {
+        lb[i] = lh[i] ? atomicAdd(&J.cursor[i], lh[i]) : 0;
+        lh[i] = 0;
+    }
+    __syncthreads();
+    for (int local = k * 256 + threadIdx.x; local < cnt; local += kSlices * 256) {
+        const size_t e = (size_t)g * J.seg_cap + local;
+        const float u[3] = {J.xyz[e * 3], J.xyz[e * 3 + 1], J.xyz[e * 3 + 2]};
+        SampleGeom sg;
+        sample_geom(J.grid, u, sg);
+        int keys[6];
+        sample_keys(K, J.grid, sg, keys);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) J.binned[lb[keys[q]] + atomicAdd(&lh[keys[q]], 1)] = (int)e;
+    }
+}
+
+__device__ __forceinline__ float entry_grad(const TfBinJob& J, int e, int ch) {
+    return J.grad_ld ? J.grad[(size_t)e * J.grad_ld + ch] : J.grad[e];
+}
+
+__device__ __forceinline__ int rl(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
+__device__ __forceinline__ float rlf(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+
+// entries a wave stages per round (LDS per wave: ER x (C + 8) floats)
+__host__ __device__ inline int entries_per_round(int cmax) { return cmax <= 16 ? 32 : 16; }
+__host__ __device__ inline int lane_group(int c) { return c <= 16 ? 16 : (c <= 32 ? 32 : 64); }
+
+// K4.  Work item = <= chunk entries of one key.  Per round each wave stages ER entries:
+//   stage  (lane = entry): val[c] = dL/dprod[c] * (line | plane value)[c] * m^2 for all C components with 16-B
+//          loads into LDS `pre[ER][C]`, plus the entry's block cell and tap weights in `meta[ER][8]` — every
+//          global load of the round is in flight at once;
+//   accum  (lanes = the footprint in memory order: row, tap, component): the wave walks its ER entries; per
+//          entry one LDS read of the cell / weight / value and a plain read-add-write on the wave's PRIVATE
+//          accumulation block (LDS float atomics measured ~100 cycles per wave-instruction, a plain RMW is 3 short
+//          LDS ops; lanes of one instruction never collide and the LDS pipe is in order).  No global access.
+//   The four private blocks are summed when the work item is flushed.
+__global__ __launch_bounds__(256) void bin_scatter_kernel(const TfBinJob J, const KeyMap K, int ER, int cmax) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wstride = ER * (cmax + 8);
+    float* pre = smem + wave * wstride;            // [ER][C]
+    float* meta = pre + ER * cmax;                 // [ER][8]: cell (int), w00, w01, w10, w11 | cell, w0, w1
+    float* blk0 = smem + 4 * wstride;              // 4 private accumulation blocks (one per wave)
+    const int total = J.chunk_off[K.nkeys];
+    const size_t rep = (size_t)(blockIdx.x % J.grads.n_rep) * J.grads.rep_stride;
+    TF_T0();
+    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+        TF_MARK(7);
+        const int key = J.chunk_off[K.nkeys + 1 + w], chunk = w - J.chunk_off[key];
+        const int beg = J.offsets[key] + chunk * J.chunk, end = min(J.offsets[key + 1], beg + J.chunk);
+        const bool is_line = key >= K.line_base[0];
+        int i = 0;
+        if (is_line) {
+            i = key >= K.line_base[2] ? 2 : (key >= K.line_base[1] ? 1 : 0);
+        } else {
+            i = key >= K.plane_base[2] ? 2 : (key >= K.plane_base[1] ? 1 : 0);
+        }
+        const int C = J.factors.n_comp[i];
+        int coff = 0;
+        for (int q = 0; q < i; ++q) coff += J.factors.n_comp[q];
+        const float* mk = J.factors.mask[i];
+        const int T1 = K.T + 1;
+        const int nblk = is_line ? (K.LB + 1) * C : T1 * T1 * C;
+        for (int q = tid; q < 4 * nblk; q += 256) blk0[q] = 0.f;
+        float* blk = blk0 + wave * nblk;
+        const int W = J.grid[mat0(i)], Hh = J.grid[mat1(i)], Gl = J.grid[vecm(i)];
+        const int t = key - K.plane_base[i], tyb = is_line ? 0 : (t / K.ntx[i]) * K.T, txb = is_line ? 0 : (t % K.ntx[i]) * K.T;
+        const int lb0 = is_line ? (key - K.line_base[i]) * K.LB : 0;
+        const bool vec = (C & 3) == 0 && (coff & 3) == 0 && (J.grad_ld & 3) == 0;
+        const int rounds = (end - beg + 4 * ER - 1) / (4 * ER);
+        TF_MARK(0);
+        for (int rd = 0; rd < rounds; ++rd) {
+            const int base = beg + (rd * 4 + wave) * ER;
+            const int nk = max(0, min(ER, end - base));
+            __syncthreads();                         // blk zeroed / previous round's staging consumed
+            TF_MARK(1);
+            // ---------------- stage: LPE = 64 / ER lanes per entry, lane `sub` takes channel quads sub, sub+LPE, ...
+            const int LPE = 64 / ER, ent = lane / LPE, sub = lane - ent * LPE;
+            if (ent < nk) {
+                const int e = J.binned[base + ent];
+                const float u[3] = {J.xyz[(size_t)e * 3], J.xyz[(size_t)e * 3 + 1], J.xyz[(size_t)e * 3 + 2]};
+                const Tap2 tp = make_tap2(u[mat0(i)], u[mat1(i)], W, Hh);
+                const Tap1 tl = make_tap1(u[vecm(i)], Gl);
+                float* mrow = meta + ent * 8;
+                if (sub == 0) {
+                    if (is_line) {
+                        int l0;
+                        float lf;
+                        tap_floor(u[vecm(i)], Gl, l0, lf);
+                        reinterpret_cast<int*>(mrow)[0] = min(max(l0, 0), Gl - 1) - lb0;
+                        mrow[1] = tl.w0;             // weights are already zero for out-of-range taps
+                        mrow[2] = tl.w1;
+                    } else {
+                        int x0, y0;
+                        float fx, fy;
+                        tap_floor(u[mat0(i)], W, x0, fx);
+                        tap_floor(u[mat1(i)], Hh, y0, fy);
+                        reinterpret_cast<int*>(mrow)[0] = (min(max(y0, 0), Hh - 1) - tyb) * T1 + min(max(x0, 0), W - 1) - txb;
+                        mrow[1] = tp.w00; mrow[2] = tp.w01; mrow[3] = tp.w10; mrow[4] = tp.w11;
+                    }
+                }
+                const float df = J.grad_ld ? 0.f : J.grad[e];
+                const float* grow = J.grad_ld ? J.grad + (size_t)e * J.grad_ld + coff : nullptr;
+                float* dst = pre + ent * C;
+                if (vec) {
+                    for (int c = 4 * sub; c < C; c += 4 * LPE) {
+                        float4_t v = is_line ? bilerp4(J.factors.plane[i], C, tp, c) : lerp4(J.factors.line[i], C, tl, c);
+                        v *= grow ? ld4(grow + c) : (float4_t){df, df, df, df};
+                        if (mk) {
+                            const float4_t m = ld4(mk + c);
+                            v *= m * m;
+                        }
+                        *reinterpret_cast<float4_t*>(dst + c) = v;
+                    }
+                } else {
+                    for (int c = sub; c < C; c += LPE) {
+                        float v = is_line ? bilerp1(J.factors.plane[i], C, tp, c) : lerp1(J.factors.line[i], C, tl, c);
+                        v *= grow ? grow[c] : df;
+                        if (mk) v *= mk[c] * mk[c];
+                        dst[c] = v;
+                    }
+                }
+            }
+            __syncthreads();
+            TF_MARK(2);
+            // ---------------- accumulate (private block, plain read-add-write)
+            const int nfoot = is_line ? 2 * C : 4 * C;
+            for (int j = lane; j < nfoot; j += 64) {
+                int row = 0, o = j;
+                if (!is_line) {
+                    row = j >= 2 * C;
+                    o = j - (row ? 2 * C : 0);
+                }
+                const int tx = o >= C, c = o - (tx ? C : 0);
+                const int lane_off = (row * T1 + tx) * C + c, wsel = 1 + row * 2 + tx;
+                for (int k = 0; k < nk; ++k) {
+                    const float* mrow = meta + k * 8;
+                    const int a = reinterpret_cast<const int*>(mrow)[0] * C + lane_off;
+                    blk[a] = fmaf(pre[k * C + c], mrow[wsel], blk[a]);
+                }
+            }
+        }
+        __syncthreads();
+        TF_MARK(3);
+        // ---------------- flush the block: contiguous rows of (T+1) x C (or C) floats
+        if (!is_line) {
+            float* gp = J.grads.plane[i];
+            for (int q = tid; q < nblk; q += 256) {
+                const float v = (blk0[q] + blk0[nblk + q]) + (blk0[2 * nblk + q] + blk0[3 * nblk + q]);
+                if (v == 0.f) continue;
+                const int c = q % C, cell = q / C, yy = tyb + cell / T1, xx = txb + cell % T1;
+                if (yy < Hh && xx < W) atomicAdd(gp + ((size_t)yy * W + xx) * C + c, v);
+            }
+        } else {
+            float* gl = J.grads.line[i] + rep;
+            for (int q = tid; q < nblk; q += 256) {
+                const float v = (blk0[q] + blk0[nblk + q]) + (blk0[2 * nblk + q] + blk0[3 * nblk + q]);
+                if (v == 0.f) continue;
+                const int c = q % C, ent = lb0 + q / C;
+                if (ent < Gl) atomicAdd(gl + (size_t)ent * C + c, v);
+            }
+        }
+        __syncthreads();
+        TF_MARK(4);
+    }
+    TF_FLUSH();
+}
+
+}  // namespace
+
+extern "C" {
+
+#ifdef TF_PHASE_TIMING
+int tf_debug_phase_cycles_bin(unsigned long long* out16, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(tf_phase_cycles), sizeof(unsigned long long) * 16);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(tf_phase_cycles), z, sizeof(z));
+    }
+    return (int)e;
+}
+#endif
+
+int tf_bin_nkeys(const int grid[3], int tile, int bucket) { return make_keymap(grid, tile, bucket).nkeys; }
+
+int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const KeyMap K = make_keymap(job->grid, job->tile, job->bucket);
+    if (K.nkeys != job->nkeys || K.nkeys > 12000) return (int)hipErrorInvalidValue;
+    int cmax = job->factors.n_comp[0];
+    for (int i = 1; i < 3; ++i) cmax = job->factors.n_comp[i] > cmax ? job->factors.n_comp[i] : cmax;
+    const size_t blk_bytes = (size_t)(job->tile + 1) * (job->tile + 1) * cmax * 4;
+    const size_t lblk_bytes = (size_t)(job->bucket + 1) * cmax * 4;
+    const int ER = entries_per_round(cmax);
+    const size_t sc_bytes = 4 * (blk_bytes > lblk_bytes ? blk_bytes : lblk_bytes) + (size_t)4 * ER * (cmax + 8) * 4;
+    if (sc_bytes > 150 * 1024) return (int)hipErrorInvalidValue;
+    int per_cu = (int)((160 * 1024) / (sc_bytes + 512));
+    per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
+    hipError_t e = hipMemsetAsync(job->hist, 0, sizeof(int) * K.nkeys, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(bin_count_kernel, dim3(TF_N_SHARDS * kSlices), dim3(256), sizeof(int) * K.nkeys, st, *job, K);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, *job, K.nkeys);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(int) * 2 * K.nkeys));
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(bin_fill_kernel, dim3(TF_N_SHARDS * kSlices), dim3(256), sizeof(int) * 2 * K.nkeys, st, *job, K);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sc_bytes);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(256 * per_cu), dim3(256), sc_bytes, st, *job, K, ER, cmax);
+    return TF_CHECK_LAUNCH();
+}
+
+}  // extern "C"

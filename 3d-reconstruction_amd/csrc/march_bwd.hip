@@ -26,6 +26,8 @@ struct BwdArgs {
     const float* rgb;            // packed per-sample colours
     float* grad_rgb;             // packed dL/d colour (out)
     int white_bg;
+    float* ent_xyz;              // binned mode: entry list (normalised xyz, dL/df) instead of scattering
+    float* ent_df;
 };
 
 __global__ __launch_bounds__(64) void march_backward_kernel(const TfField F, const TfMarchIO io, const BwdArgs B,
@@ -149,6 +151,27 @@ __global__ __launch_bounds__(64) void march_backward_kernel(const TfField F, con
     __syncthreads();
 
     // ---------------- pass 3: scatter
+    if (B.ent_xyz) {
+        // binned mode: hand every valid sample (xyz, dL/df) to tf_binned_scatter through the sharded entry list
+        const int shard = blockIdx.x & (TF_N_SHARDS - 1);
+        int base = 0;
+        if (lane == 0) {
+            const int seg_cap = ((gridDim.x + TF_N_SHARDS - 1) / TF_N_SHARDS) * N;
+            base = shard * seg_cap + atomicAdd(&io.counters[shard * TF_SHARD_STRIDE + 3], cnt);
+        }
+        base = __shfl(base, 0, 64);
+        for (int k = lane; k < cnt; k += 64) {
+            float p[3], u[3];
+            sample_pos(ray, sample_z(F, ray, ztab, io.val_idx[vbase + k]), p);
+            normalize(F, p, u);
+            const size_t e = (size_t)base + k;
+            B.ent_xyz[e * 3] = u[0];
+            B.ent_xyz[e * 3 + 1] = u[1];
+            B.ent_xyz[e * 3 + 2] = u[2];
+            B.ent_df[e] = sd[k];
+        }
+        return;
+    }
     if (F.model == TF_MODEL_VM) {
         // run-length merged scatter over chunks of 16 consecutive valid samples (tf_device.h)
         float* cbuf = smem + 3 * ncap;
@@ -214,14 +237,15 @@ int tf_reduce_replicas(const float* rep, int n_rep, int stride, int numel, float
 
 int tf_march_backward(const TfField* field, const TfMarchIO* io, const float* grad_rgb_map, const float* rgb_pre,
                       int white_bg, const float* rgb, float* grad_rgb, const TfFactorGrads* dgrads,
-                      tf_stream_t stream) {
+                      float* ent_xyz, float* ent_df, tf_stream_t stream) {
     if (io->n_rays <= 0) return 0;
     if (io->n_samples <= 0 || io->n_samples > TF_MAX_SAMPLES) return (int)hipErrorInvalidValue;
     const int ncap = (io->n_samples + 63) & ~63;
     const int ctot = field->density.n_comp[0] + field->density.n_comp[1] + field->density.n_comp[2];
     const size_t lds = (size_t)ncap * 12 + (field->model == TF_MODEL_VM ? (size_t)chunk_lds_words(ctot) * 4 : 0);
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
-    BwdArgs B{grad_rgb_map, rgb_pre, rgb, grad_rgb, white_bg};
+    if (field->model != TF_MODEL_VM) ent_xyz = ent_df = nullptr;
+    BwdArgs B{grad_rgb_map, rgb_pre, rgb, grad_rgb, white_bg, ent_xyz, ent_df};
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(march_backward_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;

@@ -437,7 +437,13 @@ __global__ __launch_bounds__(256, 1) void shade_backward_kernel(const TfShade S,
         __syncthreads();
         TF_MARK(6);
         // scatter-add into the appearance factor gradients
-        if (S.model == TF_MODEL_VM) {
+        if (G.dv_out) {
+            // binned mode: hand dL/dV to tf_binned_scatter
+            for (int it = tid; it < n * S.n_app_total; it += 256) {
+                const int smp = it / S.n_app_total, c = it % S.n_app_total;
+                G.dv_out[((size_t)s0 + smp) * S.n_app_total + c] = V[smp * L.sv + c];
+            }
+        } else if (S.model == TF_MODEL_VM) {
             // run-length merged scatter (tf_device.h): each wave takes its 16 samples as one chunk; the X and
             // H1 regions are free by now and hold the per-wave chunk buffers
             const int ctot = S.n_app_total;

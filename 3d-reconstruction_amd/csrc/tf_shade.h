@@ -6,17 +6,6 @@ namespace tf {
 
 constexpr int M = TF_TILE;
 
-// Diagnostic build only (-DTF_PHASE_TIMING, lib/libtensorf_hip_diag.so): per-phase shader-clock totals.
-#ifdef TF_PHASE_TIMING
-static __device__ unsigned long long tf_phase_cycles[16];
-#define TF_T0() unsigned long long _t = __builtin_readcyclecounter(); unsigned long long _ph[8] = {0,0,0,0,0,0,0,0}
-#define TF_MARK(i) do { unsigned long long _n = __builtin_readcyclecounter(); _ph[i] += _n - _t; _t = _n; } while (0)
-#define TF_FLUSH() do { if (threadIdx.x == 0) for (int _i = 0; _i < 8; ++_i) atomicAdd(&tf_phase_cycles[_i], _ph[_i]); } while (0)
-#else
-#define TF_T0()
-#define TF_MARK(i)
-#define TF_FLUSH()
-#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ inline int kpad16(int k) { return (k + 15) & ~15; }

@@ -141,7 +141,7 @@ class MLPRender(_MLPBase):
 class _Workspace:
     """Scratch for one forward call, carved from a single allocation (sizes follow tensorf_hip.h)."""
 
-    def __init__(self, R, N, device, save_valid, debug):
+    def __init__(self, R, N, device, save_valid, debug, binned=None):
         seg_cap = ((R + H.N_SHARDS - 1) // H.N_SHARDS) * N
         cap = seg_cap * H.N_SHARDS
         words = (N + 63) // 64
@@ -153,6 +153,11 @@ class _Workspace:
         if save_valid:
             spec += [("val_idx", R * N, torch.int32), ("val_feat", R * N, torch.float32),
                      ("grad_rgb", cap * 3, torch.float32), ("rgb_pre", R * 3, torch.float32)]
+            if binned is not None:   # binned gradient scatter (csrc/bin.hip): entry lists + sort workspace
+                nkeys, n_app = binned
+                spec += [("ent_xyz", cap * 3, torch.float32), ("ent_df", cap, torch.float32),
+                         ("dv", cap * n_app, torch.float32), ("binned", 6 * cap, torch.int32),
+                         ("bin_ints", 5 * (nkeys + 8) + 6 * cap // 256 + 64, torch.int32)]
         if debug:
             spec += [("dbg_bbox", R * words * 2, torch.int32), ("dbg_valid", R * words * 2, torch.int32),
                      ("dbg_app", R * words * 2, torch.int32)]
@@ -163,7 +168,7 @@ class _Workspace:
             setattr(self, name, self.buf[off:off + n * 4].view(dt))
             off += ((n * 4 + 255) // 256) * 256
         self.R, self.N, self.seg_cap, self.cap, self.words = R, N, seg_cap, cap, words
-        self.save_valid, self.debug = save_valid, debug
+        self.save_valid, self.debug, self.binned_cfg = save_valid, debug, binned
         self.counters2d = self.counters.view(H.N_SHARDS, H.SHARD_STRIDE)
 
 
@@ -202,6 +207,8 @@ class TensorBase(nn.Module):
 
         # kernel-side options (not part of the reference interface)
         self.t_stop = 0.0              # early ray termination threshold on transmittance (0 = off)
+        self.binned_scatter = True     # backward: counting-sorted LDS scatter (csrc/bin.hip) instead of per-tap atomics
+        self.bin_tile, self.bin_bucket, self.bin_chunk = 8, 8, 512
         self._jitter_override = None   # tests: inject the stratified jitter instead of drawing it
         self._debug_masks = False      # tests: also emit the bbox / valid bitmaps
         self._ws_cache = {}
@@ -465,7 +472,11 @@ class TensorBase(nn.Module):
         key = (R, N, str(dev), save_valid, self._debug_masks)
         ws = self._ws_cache.get(key)
         if ws is None or save_valid:
-            ws = _Workspace(R, N, dev, save_valid, self._debug_masks)
+            binned = None
+            if save_valid and not self._is_cp() and self.binned_scatter:
+                g3 = (C.c_int * 3)(*self._geom['grid'])
+                binned = (int(H.lib().tf_bin_nkeys(C.byref(g3), self.bin_tile, self.bin_bucket)), self._n_app_total())
+            ws = _Workspace(R, N, dev, save_valid, self._debug_masks, binned)
             if not save_valid:
                 self._ws_cache = {key: ws}
         return ws

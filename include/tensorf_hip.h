@@ -176,7 +176,9 @@ int tf_appfeature_points(const TfShade* shade, const float* xyz_n, int n, float*
  * density factor gradients. */
 int tf_march_backward(const TfField* field, const TfMarchIO* io, const float* grad_rgb_map, const float* rgb_pre,
                       int white_bg, const float* rgb, float* grad_rgb, const TfFactorGrads* dgrads,
-                      tf_stream_t stream);
+                      float* ent_xyz, float* ent_df, tf_stream_t stream);
+/* ent_xyz/ent_df != NULL (VM): instead of scattering, the kernel appends one entry (normalised xyz, dL/df) per
+ * density sample with a non-zero gradient to the sharded entry list (counter slot 3) for tf_binned_scatter. */
 
 /* Backward of the shading head + appearance lookup: recomputes the tile forward, then accumulates
  * gradients of w1,b1,w2,b2,w3,b3, basis and the appearance factors.  Gradient matrices use the
@@ -185,10 +187,39 @@ typedef struct TfShadeGrads {
     float* w1; float* b1; float* w2; float* b2; float* w3; float* b3;
     float* basis;          /* (app_dim, n_app_total) */
     TfFactorGrads app;
+    float* dv_out;         /* NULL, or (cap, n_app_total): write dL/dV rows for tf_binned_scatter instead of scattering */
 } TfShadeGrads;
 int tf_shade_backward(const TfShade* shade, const float* rays, int ndc, const int* counters, int seg_cap,
                       const int* app_ray, const float* app_xyz, const float* grad_rgb, const TfShadeGrads* grads,
                       tf_stream_t stream);
+
+/* Binned ("owner computes") scatter of the VM factor gradients — the backward of the plane x line lookups
+ * (autograd of tensoRF.py:216-225 / :240-260) without one global atomic per tap.
+ * Global float atomics on random 64-B pieces are request-bound (~0.4 TB/s measured), so the samples are first
+ * counting-sorted by destination: per plane i by the T x T texel tile holding their footprint base, per line i by
+ * the bucket of LB entries holding their base entry.  One workgroup then owns a (tile | bucket) chunk,
+ * accumulates all its samples in LDS ((T+1)^2 x C or (LB+1) x C floats) and flushes the block once with
+ * contiguous atomics.  Entries live in the sharded layout of the packed app list:
+ * shard g = [g*seg_cap, g*seg_cap + counters[g*TF_SHARD_STRIDE + slot]). */
+typedef struct TfBinJob {
+    TfFactors factors;        /* the field being differentiated (density or appearance), VM only */
+    TfFactorGrads grads;
+    int grid[3];
+    const int* counters;      /* sharded entry counters */
+    int slot;                 /* which counter of a shard holds the entry count */
+    int seg_cap;
+    const float* xyz;         /* (cap,3) normalised coordinates of the entries */
+    const float* grad;        /* density: (cap) dL/df per entry; appearance: (cap, ld) dL/dV rows */
+    int grad_ld;              /* 0: one scalar per entry, broadcast over components; else row stride */
+    int tile, bucket, chunk;  /* T, LB, max entries per workgroup */
+    /* workspace (ints): hist[nkeys], offsets[nkeys+1], cursor[nkeys], chunk_off[nkeys+1] followed by the
+     * work-item table (nkeys + 6*entries/chunk ints); binned[6*entries] */
+    int* hist; int* offsets; int* cursor; int* chunk_off; int* binned;
+    int nkeys;
+} TfBinJob;
+/* number of keys a job needs for (grid, T, LB): 3 plane tile maps followed by 3 line bucket maps */
+int tf_bin_nkeys(const int grid[3], int tile, int bucket);
+int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream);
 
 /* dst[j] = sum_r rep[r*stride + j], j < numel: folds the line-gradient replicas. */
 int tf_reduce_replicas(const float* rep, int n_rep, int stride, int numel, float* dst, tf_stream_t stream);
