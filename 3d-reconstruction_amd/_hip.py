@@ -63,7 +63,7 @@ class TfShade(C.Structure):
 
 class TfShadeGrads(C.Structure):
     _fields_ = [("w1", _fp), ("b1", _fp), ("w2", _fp), ("b2", _fp), ("w3", _fp), ("b3", _fp),
-                ("basis", _fp), ("app", TfFactorGrads), ("dv_out", _fp)]
+                ("basis", _fp), ("app", TfFactorGrads), ("dv_out", _fp), ("wslab", _fp), ("direct_scatter", C.c_int)]
 
 
 class TfBinJob(C.Structure):
@@ -91,6 +91,7 @@ _SIGS = {
     "tf_reduce_replicas": [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp],
     "tf_march_backward": [C.POINTER(TfField), C.POINTER(TfMarchIO), _fp, _fp, C.c_int, _fp, _fp,
                           C.POINTER(TfFactorGrads), _fp, _fp, _fp],
+    "tf_shade_backward_wslab_floats": [C.POINTER(TfShade)],
     "tf_bin_nkeys": [C.POINTER(C.c_int * 3), C.c_int, C.c_int],
     "tf_binned_scatter": [C.POINTER(TfBinJob), _fp],
     "tf_shade_backward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp,
@@ -115,6 +116,7 @@ def lib():
             fn.argtypes = args
             fn.restype = C.c_int
         L.tf_build_info.restype = C.c_char_p
+        L.tf_shade_backward_wslab_floats.restype = C.c_size_t
         _lib = L
     return _lib
 

@@ -105,7 +105,8 @@ class _RenderFn(torch.autograd.Function):
         sg.w3, sg.b3 = grads['renderModule.mlp.4.weight'].data_ptr(), grads['renderModule.mlp.4.bias'].data_ptr()
         sg.basis = grads['basis_mat.weight'].data_ptr()
         sg.app = ag
-        sg.dv_out = ws.dv.data_ptr() if binned else None
+        sg.dv_out, sg.wslab = ws.dv.data_ptr(), ws.wslab.data_ptr()
+        sg.direct_scatter = 0 if binned else 1
         model._timed("tf_shade_backward", lib.tf_shade_backward, C.byref(c['shade']), c['rays'].data_ptr(),
                      int(c['ndc']), ws.counters.data_ptr(), ws.seg_cap, ws.app_ray.data_ptr(), ws.app_xyz.data_ptr(),
                      ws.grad_rgb.data_ptr(), C.byref(sg), st)
@@ -113,6 +114,7 @@ class _RenderFn(torch.autograd.Function):
             bin_job(c['shade'].app, ag, 0, ws.app_xyz, ws.dv, model._n_app_total(), "app")
         model._timed("tf_reduce_replicas", lib.tf_reduce_replicas, rep0, N_REP, line_len, line_len, flat.data_ptr(), st)
         out = tuple(grads[n] if p.requires_grad else None for n, p in named)
+        ws.busy = False     # stream order: the next forward that takes this workspace runs after these kernels
         ctx.c = None
         return (None,) * 8 + out
 
@@ -121,6 +123,9 @@ def render_with_grad(model, rays, mask, white_bg, is_train, ndc_ray, N_samples):
     if model.shadingMode in ('SH', 'RGB'):
         raise H.HipError("training with the SH / RGB heads is not implemented in the HIP backward "
                          "(the reference cannot construct them either, models/tensorBase.py:89-98)")
-    named = [(n, p) for n, p in model.named_parameters()]
-    names = tuple(n for n, _ in named)
-    return _RenderFn.apply(model, rays, mask, white_bg, is_train, ndc_ray, N_samples, names, *[p for _, p in named])
+    cache = model._named_cache
+    if cache is None or any(a is not b for a, b in zip(cache[1], model.parameters())) or \
+            len(cache[1]) != sum(1 for _ in model.parameters()):
+        named = list(model.named_parameters())
+        cache = model._named_cache = (tuple(n for n, _ in named), [p for _, p in named])
+    return _RenderFn.apply(model, rays, mask, white_bg, is_train, ndc_ray, N_samples, cache[0], *cache[1])

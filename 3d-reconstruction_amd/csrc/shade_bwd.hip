@@ -1,7 +1,7 @@
 // shade_bwd.hip — backward of the shading head + appearance lookup (autograd of tensoRF.py:230-263 /
 // :388-415 and mlp.py:27-155).   gfx950, wave64, fp32 MFMA.
 //
-// One persistent 256-thread workgroup per CU walks 64-sample tiles of the packed app list.  Per tile it
+// One persistent 512-thread workgroup (8 waves, 2 per SIMD) per CU walks 64-sample tiles of the packed app list.  Per tile it
 // recomputes the forward (gather -> V, basis -> feat, PE -> X, two hidden layers -> H1, H2, output) in
 // LDS, then back-propagates dL/dc:
 //     do  = dL/dc . c(1-c)                         dW3 += do^T H2          db3 += sum do
@@ -10,8 +10,11 @@
 //     dX  = W1^T dZ1             (in place of X)   dfeat = dX[:, :D] + PE'(feat) . dX[:, PE cols]
 //     dB += dfeat^T V                               dV = B^T dfeat (in place of V)
 //     dP / dL scatter-add with float atomics (4 lanes per sample, channel-last gradients).
-// All weight-gradient GEMMs accumulate across the workgroup's tiles in MFMA accumulator registers
-// (sample index = MFMA k dimension) and are flushed once per workgroup.
+// The weight-gradient GEMMs (sample index = MFMA k dimension) accumulate into a per-workgroup SLAB in global
+// memory (L2 / Infinity-Cache resident, accumulator-fragment order: one 16-B load + store per lane and 16x16
+// tile and sample tile), summed over workgroups by wslab_reduce_kernel.  Nothing but six scalars lives in
+// registers across tiles, which keeps the kernel at 2 waves per SIMD without scratch (kernels that spill
+// cannot be replayed from a hipGraph on this stack).
 #include "tf_shade.h"
 
 using namespace tf;
@@ -83,12 +86,22 @@ __host__ __device__ inline BwdLds bwd_lds(const TfShade& S) {
     return L;
 }
 
-// NF = feature_c/64, NB = ceil(app_dim/16) (1..2), KT1 = max k-tiles of the first layer kept in registers.
-template <int NF, int NB, int KT1>
-__global__ __launch_bounds__(256, 1) void shade_backward_kernel(const TfShade S, const TileSrc src,
+// floats of one workgroup's weight-gradient slab: dW2 | dW1 | dB tiles of 256 floats each
+__host__ __device__ inline size_t wslab_floats(const TfShade& S) {
+    const int FT = S.feature_c / 16, kt1 = kpad16(S.in_c) / 16, NB = (S.app_dim + 15) / 16, ktB = kpad16(S.n_app_total) / 16;
+    return (size_t)(FT * FT + FT * kt1 + NB * ktB) * 256;
+}
+
+// FT = feature_c/16 hidden feature tiles (4 or 8), NB = ceil(app_dim/16) (1..2), KT1 = upper bound of the first
+// layer's k tiles kept in registers.  512 threads = 8 waves = 2 per SIMD (256 registers each, no scratch:
+// kernels that spill cannot be replayed from a hipGraph on this stack).
+// Wave w: feature tile ft = w % FT, sample group sg = w / FT (SG = 8/FT groups of NSW = 4/SG sample tiles).
+template <int FT, int NB, int KT1>
+__global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S, const TileSrc src,
                                                                  const float* __restrict__ grad_rgb,
                                                                  const TfShadeGrads G) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NT = 512, NW = 8, SG = NW / FT, NSW = 4 / SG, NW2 = FT / SG, KT1S = KT1 / SG, KTBW = 3;
     const BwdLds L = bwd_lds(S);
     float* V = lds + L.offV;
     float* X = lds + L.offX;
@@ -103,12 +116,15 @@ __global__ __launch_bounds__(256, 1) void shade_backward_kernel(const TfShade S,
     int* pre = reinterpret_cast<int*>(lds + L.offPre);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int FC = S.feature_c, kp1 = kpad16(S.in_c), kt1 = kp1 / 16, kpB = kpad16(S.n_app_total), ktB = kpB / 16;
-    constexpr int FT = 4 * NF;            // feature tiles of a hidden layer
-    constexpr int KTBW = 5;               // basis column tiles per wave kept in registers (n_app <= 320)
+    const int my_ft = wave % FT, my_sg = wave / FT, s_base = my_sg * NSW * 16;
+    const int lc = lane & 15, lg = lane >> 4;
 
-    // ---- accumulators that live across tiles
-    f32x4 aW2[NF][FT], aW1[NF][KT1], aB[NB][KTBW];
-    zero_acc(aW2); zero_acc(aW1); zero_acc(aB);
+    // ---- weight-gradient slab of this workgroup (fragment order: [tile][lane][4]) and the few scalars that
+    // do live in registers across tiles
+    float* slabW2 = G.wslab + (size_t)blockIdx.x * wslab_floats(S);
+    float* slabW1 = slabW2 + FT * FT * 256;
+    float* slabB = slabW1 + FT * kt1 * 256;
+    bool first = true;
     float aW3[3] = {0.f, 0.f, 0.f}, ab2 = 0.f, ab1 = 0.f, ab3 = 0.f;
 
     if (src.counters) {
@@ -156,26 +172,25 @@ __global__ __launch_bounds__(256, 1) void shade_backward_kernel(const TfShade S,
         __syncthreads();
 
         // ================= forward recompute =================
-        {   // gather -> V
-            const int smp = wave * 16 + (lane >> 2), sub = lane & 3;
+        {   // gather -> V, 8 lanes per sample
+            const int smp = wave * 8 + (lane >> 3), sub = lane & 7;
             float u[3] = {ixyz[smp * 3], ixyz[smp * 3 + 1], ixyz[smp * 3 + 2]};
             float* vrow = V + smp * L.sv;
-            app_products(S, u, sub, vrow);
-            for (int c = S.n_app_total + sub; c < kpB; c += 4) vrow[c] = 0.f;
+            app_products(S, u, sub, vrow, 8);
+            for (int c = S.n_app_total + sub; c < kpB; c += 8) vrow[c] = 0.f;
         }
         __syncthreads();
-        {   // basis -> X[:, :app_dim]
-            f32x4 acc[NB][1];
+        if (wave < 4 * NB) {   // basis -> X[:, :app_dim]: one (feature tile, sample tile) per wave
+            const int bf = wave >> 2, bs = wave & 3;
+            f32x4 acc[1][1];
             zero_acc(acc);
-            mma_block<NB, 1>(S.basis, kpB, 0, V, L.sv, wave * 16, ktB, acc);
-            const int smp = wave * 16 + (lane & 15), g = lane >> 4;
+            mma_block<1, 1>(S.basis, kpB, 16 * bf, V, L.sv, 16 * bs, ktB, acc);
+            const int smp = 16 * bs + lc;
 #pragma unroll
-            for (int i = 0; i < NB; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int f = 16 * i + 4 * g + e;
-                    if (f < S.app_dim) X[smp * L.sx + f] = acc[i][0][e];
-                }
+            for (int e = 0; e < 4; ++e) {
+                const int f = 16 * bf + 4 * lg + e;
+                if (f < S.app_dim) X[smp * L.sx + f] = acc[0][0][e];
+            }
         }
         if (tid < M) {
 #pragma unroll
@@ -188,7 +203,7 @@ __global__ __launch_bounds__(256, 1) void shade_backward_kernel(const TfShade S,
                 const int src_k = S.pe[b].src, F = S.pe[b].freqs;
                 const int D = src_k == TF_SRC_FEAT ? S.app_dim : 3;
                 const float* mk = S.pe[b].mask;
-                for (int it = tid; it < M * D; it += 256) {
+                for (int it = tid; it < M * D; it += NT) {
                     const int smp = it / D, d = it % D;
                     float* x = X + smp * L.sx;
                     const float v = src_k == TF_SRC_FEAT ? x[d] : (src_k == TF_SRC_VIEW ? iview[smp * 3 + d] : ixyz[smp * 3 + d]);
@@ -208,55 +223,47 @@ __global__ __launch_bounds__(256, 1) void shade_backward_kernel(const TfShade S,
                 }
                 off += 2 * D * F;
             }
-            for (int it = tid; it < M * (kp1 - S.in_c); it += 256) {
+            for (int it = tid; it < M * (kp1 - S.in_c); it += NT) {
                 const int smp = it / (kp1 - S.in_c), c = S.in_c + it % (kp1 - S.in_c);
                 X[smp * L.sx + c] = 0.f;
             }
         }
         __syncthreads();
         {   // layer 1 -> H1
-            f32x4 acc[NF][4];
+            f32x4 acc[1][NSW];
             zero_acc(acc);
-            mma_block<NF, 4>(S.w1, kp1, 16 * NF * wave, X, L.sx, 0, kt1, acc);
-            const int c = lane & 15, g = lane >> 4;
+            mma_block<1, NSW>(S.w1, kp1, 16 * my_ft, X, L.sx, s_base, kt1, acc);
+            const int f = 16 * my_ft + 4 * lg;
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(S.b1 + f);
 #pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                const int f = 16 * (NF * wave + i) + 4 * g;
-                const f32x4 bias = *reinterpret_cast<const f32x4*>(S.b1 + f);
+            for (int j = 0; j < NSW; ++j) {
+                f32x4 h = acc[0][j] + bias;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x4 h = acc[i][j] + bias;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) h[e] = fmaxf(h[e], 0.f);
-                    *reinterpret_cast<f32x4*>(H1 + (16 * j + c) * L.sh + f) = h;
-                }
+                for (int e = 0; e < 4; ++e) h[e] = fmaxf(h[e], 0.f);
+                *reinterpret_cast<f32x4*>(H1 + (s_base + 16 * j + lc) * L.sh + f) = h;
             }
         }
         __syncthreads();
         {   // layer 2 -> H2
-            f32x4 acc[NF][4];
+            f32x4 acc[1][NSW];
             zero_acc(acc);
-            mma_block<NF, 4>(S.w2, kpad16(FC), 16 * NF * wave, H1, L.sh, 0, FC / 16, acc);
-            const int c = lane & 15, g = lane >> 4;
+            mma_block<1, NSW>(S.w2, kpad16(FC), 16 * my_ft, H1, L.sh, s_base, FC / 16, acc);
+            const int f = 16 * my_ft + 4 * lg;
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(S.b2 + f);
 #pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                const int f = 16 * (NF * wave + i) + 4 * g;
-                const f32x4 bias = *reinterpret_cast<const f32x4*>(S.b2 + f);
+            for (int j = 0; j < NSW; ++j) {
+                f32x4 h = acc[0][j] + bias;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x4 h = acc[i][j] + bias;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) h[e] = fmaxf(h[e], 0.f);
-                    *reinterpret_cast<f32x4*>(H2 + (16 * j + c) * L.sh + f) = h;
-                }
+                for (int e = 0; e < 4; ++e) h[e] = fmaxf(h[e], 0.f);
+                *reinterpret_cast<f32x4*>(H2 + (s_base + 16 * j + lc) * L.sh + f) = h;
             }
         }
         __syncthreads();
-        {   // output layer, sigmoid, do = dL/dc * c (1 - c)
-            const int smp = tid >> 2, sub = tid & 3;
+        {   // output layer, sigmoid, do = dL/dc * c (1 - c); 8 lanes per sample
+            const int smp = tid >> 3, sub = tid & 7;
             const float* h = H2 + smp * L.sh;
             float o[3] = {0.f, 0.f, 0.f};
-            for (int f = sub * 4; f < FC; f += 16) {
+            for (int f = sub * 4; f < FC; f += 32) {
                 const f32x4 hv = *reinterpret_cast<const f32x4*>(h + f);
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
@@ -266,11 +273,15 @@ __global__ __launch_bounds__(256, 1) void shade_backward_kernel(const TfShade S,
                 }
             }
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) o[ch] = quad_sum(o[ch]);
+            for (int ch = 0; ch < 3; ++ch) {
+                o[ch] = quad_sum(o[ch]);
+                o[ch] += __shfl_xor(o[ch], 4, 64);
+            }
             if (sub < 3) {
+                const float ov = sub == 0 ? o[0] : (sub == 1 ? o[1] : o[2]);
                 float d = 0.f;
                 if (smp < n) {
-                    const float c = 1.f / (1.f + expf(-(o[sub] + S.b3[sub])));
+                    const float c = 1.f / (1.f + expf(-(ov + S.b3[sub])));
                     d = grad_rgb[((size_t)s0 + smp) * 3 + sub] * (c * (1.f - c));
                 }
                 dO[smp * 4 + sub] = d;
@@ -280,20 +291,18 @@ __global__ __launch_bounds__(256, 1) void shade_backward_kernel(const TfShade S,
         TF_MARK(0);
 
         // ================= backward =================
-        {   // per-feature pass: dW3, db3, dZ2 (in place of H2), db2.  2 threads per feature (sample halves)
-            const int f = tid % FC, half = tid / FC;
-            if (half < 2 && FC <= 128) {
-                const float w0 = S.w3[f], w1 = S.w3[FC + f], w2 = S.w3[2 * FC + f];
-                for (int s = half * 32; s < half * 32 + 32; ++s) {
-                    const float d0 = dO[s * 4], d1 = dO[s * 4 + 1], d2 = dO[s * 4 + 2];
-                    const float h = H2[s * L.sh + f];
-                    aW3[0] = fmaf(d0, h, aW3[0]);
-                    aW3[1] = fmaf(d1, h, aW3[1]);
-                    aW3[2] = fmaf(d2, h, aW3[2]);
-                    const float dz = h > 0.f ? fmaf(d2, w2, fmaf(d1, w1, d0 * w0)) : 0.f;
-                    H2[s * L.sh + f] = dz;
-                    ab2 += dz;
-                }
+        const int pf = tid % FC, pslice = tid / FC, pspan = M / (NT / FC);   // per-feature passes: thread -> (f, sample slice)
+        {   // dW3, db3, dZ2 (in place of H2), db2
+            const float w0 = S.w3[pf], w1 = S.w3[FC + pf], w2 = S.w3[2 * FC + pf];
+            for (int s = pslice * pspan; s < (pslice + 1) * pspan; ++s) {
+                const float d0 = dO[s * 4], d1 = dO[s * 4 + 1], d2 = dO[s * 4 + 2];
+                const float h = H2[s * L.sh + pf];
+                aW3[0] = fmaf(d0, h, aW3[0]);
+                aW3[1] = fmaf(d1, h, aW3[1]);
+                aW3[2] = fmaf(d2, h, aW3[2]);
+                const float dz = h > 0.f ? fmaf(d2, w2, fmaf(d1, w1, d0 * w0)) : 0.f;
+                H2[s * L.sh + pf] = dz;
+                ab2 += dz;
             }
             if (tid < 3) {
                 float a = 0.f;
@@ -303,83 +312,95 @@ __global__ __launch_bounds__(256, 1) void shade_backward_kernel(const TfShade S,
         }
         __syncthreads();
         TF_MARK(1);
-        // dW2[f2][f1] += sum_s dZ2[s][f2] H1[s][f1]
-        mma_gen<NF, FT, COL, COL>(H2, L.sh, 16 * NF * wave, H1, L.sh, 0, M / 16, aW2);
+        {   // dW2[f2][f1] += sum_s dZ2[s][f2] H1[s][f1]
+            f32x4 aW2[1][NW2];
+#pragma unroll
+            for (int j = 0; j < NW2; ++j) {
+                float* sp = slabW2 + ((size_t)(my_ft * FT + NW2 * my_sg + j) * 64 + lane) * 4;
+                aW2[0][j] = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(sp);
+            }
+            mma_gen<1, NW2, COL, COL>(H2, L.sh, 16 * my_ft, H1, L.sh, 16 * NW2 * my_sg, M / 16, aW2);
+#pragma unroll
+            for (int j = 0; j < NW2; ++j)
+                *reinterpret_cast<f32x4*>(slabW2 + ((size_t)(my_ft * FT + NW2 * my_sg + j) * 64 + lane) * 4) = aW2[0][j];
+        }
         __syncthreads();   // every wave is done reading H1 for dW2
         TF_MARK(2);
         {   // dH1[f1][s] = sum_f2 W2[f2][f1] dZ2[s][f2];  dZ1 = dH1 . [H1 > 0] written in place of H1
-            f32x4 acc[NF][4];
+            f32x4 acc[1][NSW];
             zero_acc(acc);
-            mma_gen<NF, 4, COL, ROW>(S.w2, kpad16(FC), 16 * NF * wave, H2, L.sh, 0, FC / 16, acc);
-            const int c = lane & 15, g = lane >> 4;
+            mma_gen<1, NSW, COL, ROW>(S.w2, kpad16(FC), 16 * my_ft, H2, L.sh, s_base, FC / 16, acc);
+            const int f = 16 * my_ft + 4 * lg;
 #pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                const int f = 16 * (NF * wave + i) + 4 * g;
+            for (int j = 0; j < NSW; ++j) {
+                float* hp = H1 + (s_base + 16 * j + lc) * L.sh + f;
+                const f32x4 h = *reinterpret_cast<const f32x4*>(hp);
+                f32x4 dz;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float* hp = H1 + (16 * j + c) * L.sh + f;
-                    const f32x4 h = *reinterpret_cast<const f32x4*>(hp);
-                    f32x4 dz;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) dz[e] = h[e] > 0.f ? acc[i][j][e] : 0.f;
-                    *reinterpret_cast<f32x4*>(hp) = dz;
-                }
+                for (int e = 0; e < 4; ++e) dz[e] = h[e] > 0.f ? acc[0][j][e] : 0.f;
+                *reinterpret_cast<f32x4*>(hp) = dz;
             }
         }
         __syncthreads();
         TF_MARK(3);
         {   // db1 += column sums of dZ1
-            const int f = tid % FC, half = tid / FC;
-            if (half < 2 && FC <= 128) {
-                float a = 0.f;
-                for (int s = half * 32; s < half * 32 + 32; ++s) a += H1[s * L.sh + f];
-                ab1 += a;
-            }
+            float a = 0.f;
+            for (int s = pslice * pspan; s < (pslice + 1) * pspan; ++s) a += H1[s * L.sh + pf];
+            ab1 += a;
         }
-        // dW1[f][k] += sum_s dZ1[s][f] X[s][k]: dZ1 fragments are read once per k-group and reused for every
-        // k tile of X
-        {
-            const int r = lane & 15, kq = lane >> 4;
+        // dW1[f][k] += sum_s dZ1[s][f] X[s][k]: dZ1 fragments are read once per k-group and reused for every k tile
+        // this wave owns (k tiles my_sg, my_sg + SG, ...)
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {      // two passes over the k tiles: half the accumulator registers
+            constexpr int KH = KT1S / 2;
+            f32x4 aW1[KH];
+#pragma unroll
+            for (int q = 0; q < KH; ++q) {
+                const int j = my_sg + SG * (half * KH + q);
+                aW1[q] = (first || j >= kt1) ? (f32x4){0.f, 0.f, 0.f, 0.f}
+                                             : *reinterpret_cast<const f32x4*>(slabW1 + ((size_t)(my_ft * kt1 + j) * 64 + lane) * 4);
+            }
 #pragma unroll 1
             for (int kg = 0; kg < M / 16; ++kg) {
-                const int ks = 16 * kg + 4 * kq;
-                f32x4 a[NF];
+                const int ks = 16 * kg + 4 * lg;
+                const f32x4 a = ldfrag<COL>(H1, L.sh, 16 * my_ft + lc, ks);
 #pragma unroll
-                for (int i = 0; i < NF; ++i) a[i] = ldfrag<COL>(H1, L.sh, 16 * (NF * wave + i) + r, ks);
-#pragma unroll
-                for (int j = 0; j < KT1; ++j) {
+                for (int q = 0; q < KH; ++q) {
+                    const int j = my_sg + SG * (half * KH + q);
                     if (j < kt1) {
-                        const f32x4 b = ldfrag<COL>(X, L.sx, 16 * j + r, ks);
+                        const f32x4 b = ldfrag<COL>(X, L.sx, 16 * j + lc, ks);
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-#pragma unroll
-                            for (int i = 0; i < NF; ++i)
-                                aW1[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[e], aW1[i][j], 0, 0, 0);
+                            aW1[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], aW1[q], 0, 0, 0);
                     }
                 }
+            }
+#pragma unroll
+            for (int q = 0; q < KH; ++q) {
+                const int j = my_sg + SG * (half * KH + q);
+                if (j < kt1) *reinterpret_cast<f32x4*>(slabW1 + ((size_t)(my_ft * kt1 + j) * 64 + lane) * 4) = aW1[q];
             }
         }
         __syncthreads();   // dW1 finished reading X; the H2 region (dZ2) is free
         TF_MARK(4);
-        for (int it = tid; it < M * S.app_dim; it += 256) {   // feat copy for the PE derivative
+        for (int it = tid; it < M * S.app_dim; it += NT) {   // feat copy for the PE derivative
             const int smp = it / S.app_dim, d = it % S.app_dim;
             Fs[smp * L.sf + d] = X[smp * L.sx + d];
         }
         __syncthreads();
-        // dX[k][s] = sum_f W1[f][k] dZ1[s][f], written in place of X; wave w owns k tiles w, w+4, ...
-        for (int kt = wave; kt < kt1; kt += 4) {
+        // dX[k][s] = sum_f W1[f][k] dZ1[s][f], written in place of X; wave w owns k tiles w, w+8, ...
+        for (int kt = wave; kt < kt1; kt += NW) {
             f32x4 acc[1][4];
             zero_acc(acc);
             mma_gen<1, 4, COL, ROW>(S.w1, kp1, 16 * kt, H1, L.sh, 0, FC / 16, acc);
-            const int c = lane & 15, g = lane >> 4;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<f32x4*>(X + (16 * j + c) * L.sx + 16 * kt + 4 * g) = acc[0][j];
+                *reinterpret_cast<f32x4*>(X + (16 * j + lc) * L.sx + 16 * kt + 4 * lg) = acc[0][j];
         }
         __syncthreads();
         TF_MARK(5);
         {   // dfeat = dX[:, :D] + PE'(feat): d/dx [sin(x 2^k) m_s] = cos(.) 2^k m_s,  d/dx [cos(.) m_c] = -sin(.) 2^k m_c
-            for (int it = tid; it < M * 16 * NB; it += 256) {
+            for (int it = tid; it < M * 16 * NB; it += NT) {
                 const int smp = it / (16 * NB), d = it % (16 * NB);
                 float gsum = 0.f;
                 if (d < S.app_dim) {
@@ -410,138 +431,149 @@ __global__ __launch_bounds__(256, 1) void shade_backward_kernel(const TfShade S,
             }
         }
         __syncthreads();
-        // dB[f][c] += sum_s dfeat[s][f] V[s][c]; wave w owns column tiles w, w+4, ...
+        // dB[f][c] += sum_s dfeat[s][f] V[s][c]; wave w owns column tiles w, w+8, ...
+        for (int ct = wave; ct < ktB; ct += NW) {
+            f32x4 one[NB][1];
 #pragma unroll
-        for (int jj = 0; jj < KTBW; ++jj) {
-            const int ct = wave + 4 * jj;
-            if (ct < ktB) {
-                f32x4 one[NB][1];
+            for (int i = 0; i < NB; ++i)
+                one[i][0] = first ? (f32x4){0.f, 0.f, 0.f, 0.f}
+                                  : *reinterpret_cast<const f32x4*>(slabB + ((size_t)(i * ktB + ct) * 64 + lane) * 4);
+            mma_gen<NB, 1, COL, COL>(Fd, L.sf, 0, V, L.sv, 16 * ct, M / 16, one);
 #pragma unroll
-                for (int i = 0; i < NB; ++i) one[i][0] = aB[i][jj];
-                mma_gen<NB, 1, COL, COL>(Fd, L.sf, 0, V, L.sv, 16 * ct, M / 16, one);
-#pragma unroll
-                for (int i = 0; i < NB; ++i) aB[i][jj] = one[i][0];
-            }
+            for (int i = 0; i < NB; ++i)
+                *reinterpret_cast<f32x4*>(slabB + ((size_t)(i * ktB + ct) * 64 + lane) * 4) = one[i][0];
         }
         __syncthreads();   // dB finished reading V
         // dV[c][s] = sum_f B[f][c] dfeat[s][f], written in place of V
-        for (int ct = wave; ct < ktB; ct += 4) {
+        for (int ct = wave; ct < ktB; ct += NW) {
             f32x4 acc[1][4];
             zero_acc(acc);
             mma_gen<1, 4, COL, ROW>(S.basis, kpB, 16 * ct, Fd, L.sf, 0, NB, acc);
-            const int c = lane & 15, g = lane >> 4;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<f32x4*>(V + (16 * j + c) * L.sv + 16 * ct + 4 * g) = acc[0][j];
+                *reinterpret_cast<f32x4*>(V + (16 * j + lc) * L.sv + 16 * ct + 4 * lg) = acc[0][j];
         }
         __syncthreads();
         TF_MARK(6);
-        // scatter-add into the appearance factor gradients
-        if (G.dv_out) {
-            // binned mode: hand dL/dV to tf_binned_scatter
-            for (int it = tid; it < n * S.n_app_total; it += 256) {
-                const int smp = it / S.n_app_total, c = it % S.n_app_total;
-                G.dv_out[((size_t)s0 + smp) * S.n_app_total + c] = V[smp * L.sv + c];
-            }
-        } else if (S.model == TF_MODEL_VM) {
-            // run-length merged scatter (tf_device.h): each wave takes its 16 samples as one chunk; the X and
-            // H1 regions are free by now and hold the per-wave chunk buffers
-            const int ctot = S.n_app_total;
-            float* cbuf = X + wave * chunk_lds_words(ctot);
-            const int ns = min(kChunk, n - wave * 16);
-            if (ns > 0) {
-                auto u_of = [&](int s_, float* u) {
-                    const int smp = wave * 16 + s_;
-                    u[0] = ixyz[smp * 3]; u[1] = ixyz[smp * 3 + 1]; u[2] = ixyz[smp * 3 + 2];
-                };
-                vm_chunk_gather(S.app, S.grid, ctot, ns, u_of, cbuf, lane);
-            }
-            __syncthreads();
-            if (ns > 0) {
-                auto dprod = [&](int s_, int c) { return V[(wave * 16 + s_) * L.sv + c]; };
-                vm_chunk_merge_scatter(S.app, G.app, S.grid, ctot, ns, dprod, cbuf, lane);
-            }
-        } else {
-            const int nit = pair_iters(S.model, S.app);
-            PairVals cur, nxt;
-            bool have = false;
-            for (int pr = 0; pr < 8; ++pr) {
-                const int sA = wave * 16 + 2 * pr, sB = sA + 1;
-                if (sA >= n) break;
-                const float uA[3] = {ixyz[sA * 3], ixyz[sA * 3 + 1], ixyz[sA * 3 + 2]};
-                const float uB[3] = {ixyz[sB * 3], ixyz[sB * 3 + 1], ixyz[sB * 3 + 2]};
-                const float* dvA = V + sA * L.sv;
-                const float* dvB = V + sB * L.sv;
-                auto dprod = [&](int s, int, int c) { return (s ? dvB : dvA)[c]; };
-                for (int it = 0; it < nit; ++it) {
-                    cp_pair_gather(S.app, G.app, S.grid, uA, uB, true, sB < n, dprod, lane, it, nxt);
-                    if (have) pair_commit(cur);
-                    cur = nxt;
-                    have = true;
-                }
-            }
-            if (have) pair_commit(cur);
+        // hand dL/dV to the scatter stage (tf_binned_scatter for VM, app_direct_scatter_kernel otherwise)
+        for (int it = tid; it < n * S.n_app_total; it += NT) {
+            const int smp = it / S.n_app_total, c = it % S.n_app_total;
+            G.dv_out[((size_t)s0 + smp) * S.n_app_total + c] = V[smp * L.sv + c];
         }
+        first = false;
         __syncthreads();
         TF_MARK(7);
     }
     TF_FLUSH();
 
-    // ================= flush the workgroup's weight gradients =================
+    // ================= the per-feature scalars (the GEMM gradients are in the slab) =================
     {
-        const int c = lane & 15, g = lane >> 4;
-#pragma unroll
-        for (int i = 0; i < NF; ++i) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int f = 16 * (NF * wave + i) + 4 * g + e;
-#pragma unroll
-                for (int j = 0; j < FT; ++j) atomicAdd(G.w2 + (size_t)f * FC + 16 * j + c, aW2[i][j][e]);
-#pragma unroll
-                for (int j = 0; j < KT1; ++j) {
-                    const int k = 16 * j + c;
-                    if (j < kt1 && k < S.in_c) atomicAdd(G.w1 + (size_t)f * S.in_c + k, aW1[i][j][e]);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int f = 16 * i + 4 * g + e;
-#pragma unroll
-                for (int jj = 0; jj < KTBW; ++jj) {
-                    const int cc = 16 * (wave + 4 * jj) + c;
-                    if (f < S.app_dim && cc < S.n_app_total) atomicAdd(G.basis + (size_t)f * S.n_app_total + cc, aB[i][jj][e]);
-                }
-            }
-        const int f = tid % FC, half = tid / FC;
-        if (half < 2 && FC <= 128) {
-            atomicAdd(G.w3 + f, aW3[0]);
-            atomicAdd(G.w3 + FC + f, aW3[1]);
-            atomicAdd(G.w3 + 2 * FC + f, aW3[2]);
-            atomicAdd(G.b2 + f, ab2);
-            atomicAdd(G.b1 + f, ab1);
-        }
+        const int pf = tid % FC;
+        atomicAdd(G.w3 + pf, aW3[0]);
+        atomicAdd(G.w3 + FC + pf, aW3[1]);
+        atomicAdd(G.w3 + 2 * FC + pf, aW3[2]);
+        atomicAdd(G.b2 + pf, ab2);
+        atomicAdd(G.b1 + pf, ab1);
         if (tid < 3) atomicAdd(G.b3 + tid, ab3);
+    }
+}
+
+// Sums the workgroups' weight-gradient slabs (fragment order) into the row-major gradient matrices.  Workgroup b
+// wrote its slab iff it owned at least one tile, i.e. b < total tiles.
+__global__ __launch_bounds__(256) void wslab_reduce_kernel(const TfShade S, const int* __restrict__ counters,
+                                                           int n_wg, const TfShadeGrads G) {
+    __shared__ int s_active;
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int g = 0; g < TF_N_SHARDS; ++g) run += (counters[g * TF_SHARD_STRIDE] + M - 1) / M;
+        s_active = run < n_wg ? run : n_wg;
+    }
+    __syncthreads();
+    const int active = s_active;
+    const int FT = S.feature_c / 16, kt1 = kpad16(S.in_c) / 16, NB = (S.app_dim + 15) / 16, ktB = kpad16(S.n_app_total) / 16;
+    const size_t stride = wslab_floats(S);
+    const int total = (FT * FT + FT * kt1 + NB * ktB) * 256;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
+        float a = 0.f;
+        for (int b = 0; b < active; ++b) a += G.wslab[(size_t)b * stride + q];
+        const int tile = q >> 8, lane = (q >> 2) & 63, e = q & 3;
+        const int r = 4 * (lane >> 4) + e, c = lane & 15;
+        if (tile < FT * FT) {
+            G.w2[(size_t)(16 * (tile / FT) + r) * S.feature_c + 16 * (tile % FT) + c] = a;
+        } else if (tile < FT * FT + FT * kt1) {
+            const int t2 = tile - FT * FT, k = 16 * (t2 % kt1) + c;
+            if (k < S.in_c) G.w1[(size_t)(16 * (t2 / kt1) + r) * S.in_c + k] = a;
+        } else {
+            const int t3 = tile - FT * FT - FT * kt1, f = 16 * (t3 / ktB) + r, cc = 16 * (t3 % ktB) + c;
+            if (f < S.app_dim && cc < S.n_app_total) G.basis[(size_t)f * S.n_app_total + cc] = a;
+        }
+    }
+}
+
+// Direct scatter of dL/dV rows (TensorCP, or VM with binning disabled): one wave per pair of packed samples;
+// the gather of the next pair is issued before the atomics of the current one.
+__global__ __launch_bounds__(256) void app_direct_scatter_kernel(const TfShade S, const TileSrc src, const TfShadeGrads G) {
+    __shared__ int pre[TF_N_SHARDS + 1];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) {
+        int run = 0;
+        for (int g = 0; g < TF_N_SHARDS; ++g) {
+            pre[g] = run;
+            run += (src.counters[g * TF_SHARD_STRIDE] + M - 1) / M;
+        }
+        pre[TF_N_SHARDS] = run;
+    }
+    __syncthreads();
+    const int nit = pair_iters(S.model, S.app);
+    const int c0 = S.app.n_comp[0], c1 = S.app.n_comp[1];
+    for (int t = blockIdx.x;; t += gridDim.x) {
+        int s0, n;
+        if (!locate_tile(src, pre, t, s0, n)) break;
+        PairVals cur, nxt;
+        bool have = false;
+        for (int pr = 0; pr < 8; ++pr) {
+            const int a = wave * 16 + 2 * pr;
+            if (a >= n) break;
+            const size_t sA = (size_t)s0 + a, sB = sA + 1;
+            const bool hasB = a + 1 < n;
+            const float uA[3] = {src.app_xyz[sA * 3], src.app_xyz[sA * 3 + 1], src.app_xyz[sA * 3 + 2]};
+            const float uB[3] = {hasB ? src.app_xyz[sB * 3] : uA[0], hasB ? src.app_xyz[sB * 3 + 1] : uA[1],
+                                 hasB ? src.app_xyz[sB * 3 + 2] : uA[2]};
+            const float* dvA = G.dv_out + sA * S.n_app_total;
+            const float* dvB = G.dv_out + (hasB ? sB : sA) * S.n_app_total;
+            auto dprod = [&](int s_, int i, int c) {
+                const int off_i = S.model == TF_MODEL_VM ? (i == 0 ? 0 : (i == 1 ? c0 : c0 + c1)) : 0;
+                return (s_ ? dvB : dvA)[off_i + c];
+            };
+            for (int it = 0; it < nit; ++it) {
+                if (S.model == TF_MODEL_VM)
+                    vm_pair_gather(S.app, G.app, S.grid, uA, uB, true, hasB, dprod, lane, it, nxt);
+                else
+                    cp_pair_gather(S.app, G.app, S.grid, uA, uB, true, hasB, dprod, lane, it, nxt);
+                if (have) pair_commit(cur);
+                cur = nxt;
+                have = true;
+            }
+        }
+        if (have) pair_commit(cur);
     }
 }
 
 typedef void (*bwd_fn_t)(const TfShade, const TileSrc, const float*, const TfShadeGrads);
 
-template <int NF, int NB>
+template <int FT, int NB>
 bwd_fn_t pick_kt(int kt1) {
-    if (kt1 <= 4) return shade_backward_kernel<NF, NB, 4>;
-    if (kt1 <= 8) return shade_backward_kernel<NF, NB, 8>;
-    if (kt1 <= 12) return shade_backward_kernel<NF, NB, 12>;
+    if (kt1 <= 4) return shade_backward_kernel<FT, NB, 4>;
+    if (kt1 <= 8) return shade_backward_kernel<FT, NB, 8>;
+    if (kt1 <= 12) return shade_backward_kernel<FT, NB, 12>;
     return nullptr;
 }
 
 bwd_fn_t pick_bwd(const TfShade& S) {
     const int nb = (S.app_dim + 15) / 16, kt1 = kpad16(S.in_c) / 16;
-    if (S.head != TF_HEAD_MLP || nb > 2 || kpad16(S.n_app_total) / 16 > 20) return nullptr;
-    if (S.feature_c == 64) return nb == 1 ? pick_kt<1, 1>(kt1) : pick_kt<1, 2>(kt1);
-    if (S.feature_c == 128) return nb == 1 ? pick_kt<2, 1>(kt1) : pick_kt<2, 2>(kt1);
+    if (S.head != TF_HEAD_MLP || nb > 2 || kpad16(S.n_app_total) / 16 > 24) return nullptr;
+    if (S.feature_c == 64) return nb == 1 ? pick_kt<4, 1>(kt1) : pick_kt<4, 2>(kt1);
+    if (S.feature_c == 128) return nb == 1 ? pick_kt<8, 1>(kt1) : pick_kt<8, 2>(kt1);
     return nullptr;
 }
 
@@ -557,12 +589,15 @@ int tf_shade_backward(const TfShade* shade, const float* rays, int ndc, const in
     const BwdLds L = bwd_lds(*shade);
     const size_t bytes = (size_t)L.total * sizeof(float);
     if (bytes > 160 * 1024) return (int)hipErrorInvalidValue;
-    if (shade->model == TF_MODEL_VM && 4 * chunk_lds_words(shade->n_app_total) > M * (L.sx + 2 * L.sh))
-        return (int)hipErrorInvalidValue;   // scatter chunk buffers live in the X | H1 | H2 regions
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;
+    if (!grads->dv_out || !grads->wslab) return (int)hipErrorInvalidValue;
     TileSrc src{counters, seg_cap, 0, app_ray, app_xyz, rays, ndc};
-    hipLaunchKernelGGL(fn, dim3(256), dim3(256), bytes, (hipStream_t)stream, *shade, src, grad_rgb, *grads);
+    const int n_wg = 256;
+    hipLaunchKernelGGL(fn, dim3(n_wg), dim3(512), bytes, (hipStream_t)stream, *shade, src, grad_rgb, *grads);
+    hipLaunchKernelGGL(wslab_reduce_kernel, dim3(160), dim3(256), 0, (hipStream_t)stream, *shade, counters, n_wg, *grads);
+    if (grads->direct_scatter)
+        hipLaunchKernelGGL(app_direct_scatter_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, *shade, src, *grads);
     return TF_CHECK_LAUNCH();
 }
 
@@ -579,5 +614,8 @@ int tf_debug_phase_cycles_bwd(unsigned long long* out16, int reset) {
     return (int)e;
 }
 #endif
+
+/* floats the caller must provide in TfShadeGrads.wslab (256 workgroup slabs) */
+size_t tf_shade_backward_wslab_floats(const TfShade* shade) { return 256 * wslab_floats(*shade); }
 
 }  // extern "C"

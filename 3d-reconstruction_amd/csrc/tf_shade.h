@@ -59,7 +59,8 @@ __device__ __forceinline__ void mma_block(const float* __restrict__ Wg, int ldw,
 
 // Products (P*m)(L*m) [VM] or (L0*L1*L2)*m [CP] of one sample, channel quads sub, sub+4, ..., written to
 // vrow[0 .. n_app_total).
-__device__ __forceinline__ void app_products(const TfShade& S, const float u[3], int sub, float* vrow) {
+// `lps` lanes cooperate on one sample (lane `sub` takes channel quads sub, sub+lps, ...)
+__device__ __forceinline__ void app_products(const TfShade& S, const float u[3], int sub, float* vrow, int lps = 4) {
     if (S.model == TF_MODEL_VM) {
         VmTaps t;
         make_vm_taps(S.grid, u, t);
@@ -69,7 +70,7 @@ __device__ __forceinline__ void app_products(const TfShade& S, const float u[3],
             const int C = S.app.n_comp[i];
             const float* mk = S.app.mask[i];
             if ((C & 3) == 0 && (coff & 3) == 0) {
-                for (int q = sub; q < (C >> 2); q += 4) {
+                for (int q = sub; q < (C >> 2); q += lps) {
                     float4_t p = bilerp4(S.app.plane[i], C, t.p[i], q * 4);
                     float4_t l = lerp4(S.app.line[i], C, t.l[i], q * 4);
                     if (mk) {
@@ -80,7 +81,7 @@ __device__ __forceinline__ void app_products(const TfShade& S, const float u[3],
                     *reinterpret_cast<float4_t*>(vrow + coff + q * 4) = p * l;
                 }
             } else {
-                for (int c = sub; c < C; c += 4) {
+                for (int c = sub; c < C; c += lps) {
                     float p = bilerp1(S.app.plane[i], C, t.p[i], c);
                     float l = lerp1(S.app.line[i], C, t.l[i], c);
                     if (mk) {
@@ -99,7 +100,7 @@ __device__ __forceinline__ void app_products(const TfShade& S, const float u[3],
         Tap1 t2 = make_tap1(u[vecm(2)], S.grid[vecm(2)]);
         const float* mk = S.app.mask[0];
         if ((C & 3) == 0) {
-            for (int q = sub; q < (C >> 2); q += 4) {
+            for (int q = sub; q < (C >> 2); q += lps) {
                 float4_t v = lerp4(S.app.line[0], C, t0, q * 4);
                 v *= lerp4(S.app.line[1], C, t1, q * 4);
                 v *= lerp4(S.app.line[2], C, t2, q * 4);
@@ -107,7 +108,7 @@ __device__ __forceinline__ void app_products(const TfShade& S, const float u[3],
                 *reinterpret_cast<float4_t*>(vrow + q * 4) = v;
             }
         } else {
-            for (int c = sub; c < C; c += 4) {
+            for (int c = sub; c < C; c += lps) {
                 float v = lerp1(S.app.line[0], C, t0, c) * lerp1(S.app.line[1], C, t1, c);
                 v *= lerp1(S.app.line[2], C, t2, c);
                 if (mk) v *= mk[c];

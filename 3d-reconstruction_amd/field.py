@@ -141,7 +141,7 @@ class MLPRender(_MLPBase):
 class _Workspace:
     """Scratch for one forward call, carved from a single allocation (sizes follow tensorf_hip.h)."""
 
-    def __init__(self, R, N, device, save_valid, debug, binned=None):
+    def __init__(self, R, N, device, save_valid, debug, binned=None, train_extra=None):
         seg_cap = ((R + H.N_SHARDS - 1) // H.N_SHARDS) * N
         cap = seg_cap * H.N_SHARDS
         words = (N + 63) // 64
@@ -153,10 +153,12 @@ class _Workspace:
         if save_valid:
             spec += [("val_idx", R * N, torch.int32), ("val_feat", R * N, torch.float32),
                      ("grad_rgb", cap * 3, torch.float32), ("rgb_pre", R * 3, torch.float32)]
+            n_app, wslab = train_extra
+            spec += [("dv", cap * n_app, torch.float32), ("wslab", wslab, torch.float32)]
             if binned is not None:   # binned gradient scatter (csrc/bin.hip): entry lists + sort workspace
-                nkeys, n_app = binned
+                nkeys = binned[0]
                 spec += [("ent_xyz", cap * 3, torch.float32), ("ent_df", cap, torch.float32),
-                         ("dv", cap * n_app, torch.float32), ("binned", 6 * cap, torch.int32),
+                         ("binned", 6 * cap, torch.int32),
                          ("bin_ints", 5 * (nkeys + 8) + 6 * cap // 256 + 64, torch.int32)]
         if debug:
             spec += [("dbg_bbox", R * words * 2, torch.int32), ("dbg_valid", R * words * 2, torch.int32),
@@ -169,6 +171,7 @@ class _Workspace:
             off += ((n * 4 + 255) // 256) * 256
         self.R, self.N, self.seg_cap, self.cap, self.words = R, N, seg_cap, cap, words
         self.save_valid, self.debug, self.binned_cfg = save_valid, debug, binned
+        self.busy = False
         self.counters2d = self.counters.view(H.N_SHARDS, H.SHARD_STRIDE)
 
 
@@ -210,8 +213,11 @@ class TensorBase(nn.Module):
         self.binned_scatter = True     # backward: counting-sorted LDS scatter (csrc/bin.hip) instead of per-tap atomics
         self.bin_tile, self.bin_bucket, self.bin_chunk = 8, 8, 512
         self._jitter_override = None   # tests: inject the stratified jitter instead of drawing it
+        self.static_jitter = None      # graph capture: device tensor (R,) the harness refills before every replay
         self._debug_masks = False      # tests: also emit the bbox / valid bitmaps
         self._ws_cache = {}
+        self._train_ws = {}
+        self._named_cache = None
         self._pack_cache = {}
         self._ztab_cache = {}
         self.last = None               # workspace of the most recent forward (tests / bench statistics)
@@ -362,8 +368,8 @@ class TensorBase(nn.Module):
         kp = (cols + 15) // 16 * 16
         tag = (src.data_ptr(), src._version, rows_pad, kp)
         hit = self._pack_cache.get(key)
-        if hit is not None and hit[0] == tag:
-            return hit[1]
+        if hit is not None and hit[0] == tag and not torch.cuda.is_current_stream_capturing():
+            return hit[1]   # (while a graph is being captured the pack launch must be part of the graph)
         dst = hit[1] if hit is not None and tuple(hit[1].shape) == (rows_pad, kp) else \
             torch.empty((rows_pad, kp), dtype=torch.float32, device=src.device)
         s = src.detach().contiguous()
@@ -448,6 +454,8 @@ class TensorBase(nn.Module):
         if not ndc_ray:
             if not is_train:
                 return None, None
+            if self.static_jitter is not None:
+                return self.static_jitter, None
             j = self._jitter_override
             if j is None:
                 # same CPU-generator draw as the reference, generated straight into pinned memory so the upload
@@ -470,22 +478,40 @@ class TensorBase(nn.Module):
 
     def _workspace(self, R, N, dev, save_valid):
         key = (R, N, str(dev), save_valid, self._debug_masks)
+        if save_valid and not torch.cuda.is_current_stream_capturing():
+            # training: reuse a workspace whose backward has finished (stream order makes that safe); a
+            # workspace stays `busy` from its forward until the end of its backward
+            pool = self._train_ws.setdefault(key, [])
+            for w in pool:
+                if not w.busy:
+                    w.busy = True
+                    return w
         ws = self._ws_cache.get(key)
         if ws is None or save_valid:
             binned = None
             if save_valid and not self._is_cp() and self.binned_scatter:
                 g3 = (C.c_int * 3)(*self._geom['grid'])
                 binned = (int(H.lib().tf_bin_nkeys(C.byref(g3), self.bin_tile, self.bin_bucket)), self._n_app_total())
-            ws = _Workspace(R, N, dev, save_valid, self._debug_masks, binned)
+            extra = None
+            if save_valid:
+                sh, _keep = self._shade_desc([None, None, None], None, dev)
+                wslab = int(H.lib().tf_shade_backward_wslab_floats(C.byref(sh))) if sh.head == H.HEAD_MLP else 64
+                extra = (self._n_app_total(), wslab)
+            ws = _Workspace(R, N, dev, save_valid, self._debug_masks, binned, extra)
             if not save_valid:
                 self._ws_cache = {key: ws}
+            elif not torch.cuda.is_current_stream_capturing():
+                ws.busy = True
+                pool = self._train_ws.setdefault(key, [])
+                if len(pool) < 4:
+                    pool.append(ws)
         return ws
 
     def _timed(self, name, fn, *args):
         """Runs one C-ABI launch; when `kernel_events` is a dict, brackets it with HIP events recorded on the
         launch stream (torch's current stream) so bench.py can read per-kernel durations."""
         ev = self.kernel_events
-        if ev is None:
+        if ev is None or torch.cuda.is_current_stream_capturing():
             H.check(fn(*args), name)
             return
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

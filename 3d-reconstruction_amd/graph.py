@@ -1,0 +1,68 @@
+"""hipGraph-captured training step.
+
+At MI355X speeds one train step of this path is ~1.5 ms of GPU work launched as ~40 kernels; driving it from
+Python costs about as much host time (autograd dispatch, optimizer, ctypes), so the eager loop is launch-bound.
+`GraphedTrainStep` captures forward -> MSE -> backward -> Adam into ONE hipGraph (torch.cuda.CUDAGraph on the
+stream the C-ABI launches use) and replays it per step.  Everything data-dependent already lives on the
+device (sample counts, packed lists, bins), so the captured launch sequence is step-invariant.  Host work per
+step is: draw the stratified jitter from the CPU generator exactly like the reference (tensorBase.py:201),
+stage the batch into the static input buffers, replay.
+
+Restrictions (else use the eager path): fixed batch size / N_samples, `white_bg=True` (the random background
+draw of tensorBase.py:380 is a host decision per step), single process (the gradient all-reduce is not
+captured)."""
+import torch
+
+
+class GraphedTrainStep:
+    def __init__(self, model, optimizer, batch, n_samples, mask=None, ndc_ray=False, warmup=3):
+        self.model, self.opt = model, optimizer
+        dev = next(model.parameters()).device
+        self.rays = torch.zeros(batch, 6, device=dev)
+        self.target = torch.zeros(batch, 3, device=dev)
+        self.jitter = torch.zeros(batch, device=dev)
+        self.loss = torch.zeros((), device=dev)
+        self.n_samples, self.mask, self.ndc = n_samples, mask, ndc_ray
+        self.graph = None
+        self._warm = max(1, warmup)   # >= 1: the first eager step also caches host copies of the geometry
+        # PyTorch's whole-network capture recipe: warm-up iterations and the capture run on the same side
+        # stream, so the autograd AccumulateGrad nodes are bound to the stream that is later captured
+        self._side = torch.cuda.Stream(device=dev)
+
+    def _body(self):
+        rgb, _, _ = self.model(self.rays, self.mask, white_bg=True, is_train=True, ndc_ray=self.ndc,
+                               N_samples=self.n_samples)
+        loss = torch.mean((rgb - self.target) ** 2)
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        self.opt.step()
+        self.loss.copy_(loss.detach())
+
+    def _stage(self, rays, target):
+        self.rays.copy_(rays, non_blocking=True)
+        self.target.copy_(target, non_blocking=True)
+        j = torch.rand(rays.shape[0], 1, pin_memory=True)        # same CPU-generator draw as the reference
+        self.jitter.copy_(j.view(-1), non_blocking=True)
+
+    def step(self, rays, target):
+        """One optimisation step on (rays, target); returns the (device) loss tensor of that step."""
+        self._stage(rays, target)
+        if self.graph is not None:
+            self.graph.replay()
+            return self.loss
+        self.model.static_jitter = self.jitter
+        cur = torch.cuda.current_stream()
+        if self._warm > 0:                                        # eager warm-up steps (also sizes the pools)
+            self._warm -= 1
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                self._body()
+            cur.wait_stream(self._side)
+            return self.loss
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=self._side):
+            self._body()
+        self.graph = g
+        g.replay()                                                # capture only records; run this step now
+        return self.loss

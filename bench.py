@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--grid", type=int, default=300)
     ap.add_argument("--views", type=int, default=3)
     ap.add_argument("--no-baselines", action="store_true", help="skip the CPU / ROCm-eager baseline legs")
+    ap.add_argument("--no-graph", action="store_true", help="drive the train step eagerly instead of replaying a hipGraph")
     return ap.parse_args()
 
 
@@ -159,7 +160,9 @@ def main():
 
     # train.py:272-273 (same optimizer, same groups / learning rates); fused=True only changes how torch
     # batches the elementwise update
-    opt = torch.optim.Adam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), fused=True)
+    use_graph = args.mode == "train" and world == 1 and not args.no_graph
+    opt = torch.optim.Adam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), fused=True, capturable=use_graph)
+    graphed = recon_amd.GraphedTrainStep(model, opt, B, n_samples) if use_graph else None
     model.lazy_sample_count = True   # the renderer's 6th return value syncs only when read (train.py never reads it)
     renderer = recon_amd.OctreeRender_trilinear_fast
 
@@ -181,7 +184,11 @@ def main():
             renderer(rays[ids], model, None, chunk=B, N_samples=n_samples, white_bg=True, ndc_ray=False, device=dev,
                      is_train=False)
 
-    step = train_step if args.mode == "train" else eval_step
+    def graph_step(i):
+        ids = perm[i]
+        return graphed.step(rays[ids], targets[ids])
+
+    step = (graph_step if use_graph else train_step) if args.mode == "train" else eval_step
     torch.manual_seed(1234 + rank)
     for i in range(args.warmup):
         step(i)
@@ -195,7 +202,8 @@ def main():
     ctr_sum = torch.zeros(3, dtype=torch.int64, device=dev)
     for i in range(args.warmup, n_steps):
         step(i)
-        ctr_sum += model.last["ws"].counters2d[:, :3].sum(0)
+        if not use_graph:
+            ctr_sum += model.last["ws"].counters2d[:, :3].sum(0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -207,10 +215,31 @@ def main():
         elapsed = float(tt)
     events = model.kernel_events
     model.kernel_events = None
+    eager_ms = None
+    if use_graph:
+        # the graph replays cannot carry HIP events, so the per-kernel durations come from an eager pass of the
+        # SAME step (same kernels, same batch shapes) run right here, bracketed launch by launch with events
+        opt_e = torch.optim.Adam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), fused=True)
+        opt, model.static_jitter = opt_e, None
+        n_e = min(20, args.steps)
+        for i in range(3):
+            train_step(i)
+        model.kernel_events = {}
+        torch.cuda.synchronize()
+        te = time.perf_counter()
+        for i in range(n_e):
+            train_step(args.warmup + i)
+            ctr_sum += model.last["ws"].counters2d[:, :3].sum(0)
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - te) / n_e * 1e3
+        events = model.kernel_events
+        model.kernel_events = None
 
     if rank == 0:
         k = args.steps
         c = ctr_sum.tolist()
+        if use_graph:
+            c = [v * k / min(20, k) for v in c]     # counters were summed over the eager pass only
         stats = {"rays": B, "shaded": c[0] / k, "density": c[1] / k, "bbox": c[2] / k}
         cfg = dict(density_n_comp=model.density_n_comp, app_n_comp=model.app_n_comp, app_dim=model.app_dim,
                    featureC=model.featureC, in_c=model.renderModule.in_mlpC)
@@ -237,7 +266,9 @@ def main():
                        "mode": args.mode, "batch_per_gpu": B, "global_batch": B * world, "n_samples": n_samples,
                        "per_ray": {"in_bbox": stats["bbox"] / B, "density": stats["density"] / B,
                                    "shaded": stats["shaded"] / B},
-                       "parallelism": f"ray-sharded dp{world}", "lazy_sample_count": True},
+                       "parallelism": f"ray-sharded dp{world}", "lazy_sample_count": True,
+                       "launch": "hipGraph replay" if use_graph else "eager",
+                       "eager_ms_per_step": eager_ms},
             "roofline": roof,
             "kernels": {n: {"avg_ms": round(v["avg_ms"], 5), "GBps": round(v["GBps"], 1),
                             "TFLOPps": round(v["TFLOPps"], 2)} for n, v in kt.items()},

@@ -187,8 +187,12 @@ typedef struct TfShadeGrads {
     float* w1; float* b1; float* w2; float* b2; float* w3; float* b3;
     float* basis;          /* (app_dim, n_app_total) */
     TfFactorGrads app;
-    float* dv_out;         /* NULL, or (cap, n_app_total): write dL/dV rows for tf_binned_scatter instead of scattering */
+    float* dv_out;         /* (cap, n_app_total): dL/dV rows of the packed samples, consumed by the scatter stage */
+    float* wslab;          /* tf_shade_backward_wslab_floats() floats: per-workgroup weight-gradient slabs */
+    int direct_scatter;    /* 1: scatter dv_out with per-tap atomics inside the call (TensorCP / binning disabled);
+                            * 0: the caller runs tf_binned_scatter on dv_out */
 } TfShadeGrads;
+size_t tf_shade_backward_wslab_floats(const TfShade* shade);
 int tf_shade_backward(const TfShade* shade, const float* rays, int ndc, const int* counters, int seg_cap,
                       const int* app_ray, const float* app_xyz, const float* grad_rgb, const TfShadeGrads* grads,
                       tf_stream_t stream);

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "tensorf_hip.h")).read()
-    return sorted(set(re.findall(r"^\s*(?:int|const char\*)\s+(tf_[a-z0-9_]+)\s*\(", text, flags=re.M)))
+    return sorted(set(re.findall(r"^\s*(?:int|size_t|const char\*)\s+(tf_[a-z0-9_]+)\s*\(", text, flags=re.M)))
 
 
 def test_library_exports_every_declared_symbol(recon):

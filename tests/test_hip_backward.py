@@ -61,3 +61,41 @@ def test_adam_step_runs_on_channel_last_parameters(recon):
         losses.append(loss.item())
     assert recon.is_channel_last(model.density_plane[0]) and recon.is_channel_last(model.app_line[2])
     assert losses[-1] < losses[0], losses
+
+
+def test_graphed_train_step_matches_eager(recon):
+    """hipGraph-captured step (graph.py): replayed gradients == eager gradients on the same data and jitter.
+    lr = 0 keeps the parameters fixed, so the comparison is not blurred by Adam amplifying rounding noise."""
+    c = Case("vm_cubic_train")
+    dev = "cuda:0"
+    rays = c.rays.to(dev)
+    target = torch.from_numpy(c.expect("grad/target")).to(dev)
+    me, mg = build_model(recon, c, dev), build_model(recon, c, dev)
+    oe, og = torch.optim.SGD(me.parameters(), lr=0.0), torch.optim.SGD(mg.parameters(), lr=0.0)
+    gs = recon.GraphedTrainStep(mg, og, rays.shape[0], -1, warmup=1)
+    for it in range(4):
+        torch.manual_seed(100 + it)
+        rgb, _, _ = me(rays, None, white_bg=True, is_train=True)
+        loss = torch.mean((rgb - target) ** 2)
+        oe.zero_grad()
+        loss.backward()
+        torch.manual_seed(100 + it)
+        lg = gs.step(rays, target)
+        torch.cuda.synchronize()
+        assert abs(lg.item() - loss.item()) < 1e-6 * max(1.0, abs(loss.item()))
+        for (k, a), (_, b) in zip(me.named_parameters(), mg.named_parameters()):
+            scale = max(a.grad.abs().max().item(), 1e-12)
+            assert (a.grad - b.grad).abs().max().item() <= 1e-4 * scale, (it, k)
+    assert gs.graph is not None
+
+
+def test_graphed_adam_training_reduces_loss(recon):
+    c = Case("vm_cubic_train")
+    dev = "cuda:0"
+    model = build_model(recon, c, dev)
+    opt = torch.optim.Adam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), fused=True, capturable=True)
+    gs = recon.GraphedTrainStep(model, opt, c.rays.shape[0], -1, warmup=2)
+    rays, target = c.rays.to(dev), torch.from_numpy(c.expect("grad/target")).to(dev)
+    torch.manual_seed(0)
+    losses = [gs.step(rays, target).item() for _ in range(8)]
+    assert gs.graph is not None and losses[-1] < losses[0], losses
