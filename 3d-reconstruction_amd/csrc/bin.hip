@@ -71,6 +71,12 @@ __device__ __forceinline__ void sample_keys(const KeyMap& K, const int grid[3], 
 
 constexpr int kSlices = 8;   // workgroups per entry shard in the count / fill passes
 
+// (a kernel rather than hipMemsetAsync: the memset issued from this library was not replayed by a captured
+// hipGraph, which left the histogram un-zeroed on the second replay)
+__global__ __launch_bounds__(256) void zero_ints_kernel(int* __restrict__ p, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
+}
+
 // entries of shard g handled by slice k: local = k*256 + tid, += kSlices*256
 __global__ __launch_bounds__(256) void bin_count_kernel(const TfBinJob J, const KeyMap K) {
     extern __shared__ int lh[];
@@ -353,8 +359,8 @@ int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream) {
     if (sc_bytes > 150 * 1024) return (int)hipErrorInvalidValue;
     int per_cu = (int)((160 * 1024) / (sc_bytes + 512));
     per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
-    hipError_t e = hipMemsetAsync(job->hist, 0, sizeof(int) * K.nkeys, st);
-    if (e != hipSuccess) return (int)e;
+    hipError_t e = hipSuccess;
+    hipLaunchKernelGGL(zero_ints_kernel, dim3((K.nkeys + 255) / 256), dim3(256), 0, st, job->hist, K.nkeys);
     hipLaunchKernelGGL(bin_count_kernel, dim3(TF_N_SHARDS * kSlices), dim3(256), sizeof(int) * K.nkeys, st, *job, K);
     hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, *job, K.nkeys);
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
