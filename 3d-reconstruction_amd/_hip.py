@@ -58,7 +58,8 @@ class TfShade(C.Structure):
     _fields_ = [("model", C.c_int), ("grid", C.c_int * 3), ("app", TfFactors), ("app_dim", C.c_int),
                 ("n_app_total", C.c_int), ("head", C.c_int), ("basis", _fp), ("n_pe", C.c_int),
                 ("pe", TfPeBlock * 3), ("in_c", C.c_int), ("feature_c", C.c_int),
-                ("w1", _fp), ("b1", _fp), ("w2", _fp), ("b2", _fp), ("w3", _fp), ("b3", _fp)]
+                ("w1", _fp), ("b1", _fp), ("w2", _fp), ("b2", _fp), ("w3", _fp), ("b3", _fp),
+                ("w1t", _fp), ("w2t", _fp)]
 
 
 class TfShadeGrads(C.Structure):
@@ -83,6 +84,7 @@ _lib = None
 _SIGS = {
     "tf_pack_alpha_cells": [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp],
     "tf_pack_matrix": [_fp, C.c_int, C.c_int, _fp, C.c_int, _fp],
+    "tf_pack_matrix_t": [_fp, C.c_int, C.c_int, _fp, C.c_int, _fp],
     "tf_march_forward": [C.POINTER(TfField), C.POINTER(TfMarchIO), _fp],
     "tf_shade_forward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp],
     "tf_composite_forward": [C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp],

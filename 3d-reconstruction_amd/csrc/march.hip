@@ -228,6 +228,15 @@ __global__ __launch_bounds__(256) void pack_matrix_kernel(const float* __restric
     }
 }
 
+__global__ __launch_bounds__(256) void pack_matrix_t_kernel(const float* __restrict__ src, int rows, int cols,
+                                                            float* __restrict__ dst, int rows_pad, int kp) {
+    const int total = kp * rows_pad;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int c = i / rows_pad, r = i % rows_pad;
+        dst[i] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+    }
+}
+
 // rgb_map = sum_k w_k rgb_k (+ 1 - acc) clamped  (tensorBase.py:378-384).  8 lanes per ray; a ray's entries
 // are contiguous and in sample order, so the summation order is fixed (deterministic).
 __global__ __launch_bounds__(256) void composite_kernel(int n_rays, const int* __restrict__ app_offset,
@@ -278,6 +287,14 @@ int tf_pack_matrix(const float* src, int rows, int cols, float* dst, int rows_pa
     const int kp = (cols + 15) & ~15;
     const int total = rows_pad * kp;
     hipLaunchKernelGGL(pack_matrix_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, rows,
+                       cols, dst, rows_pad, kp);
+    return TF_CHECK_LAUNCH();
+}
+
+int tf_pack_matrix_t(const float* src, int rows, int cols, float* dst, int rows_pad, tf_stream_t stream) {
+    const int kp = (cols + 15) & ~15;
+    const int total = kp * rows_pad;
+    hipLaunchKernelGGL(pack_matrix_t_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, rows,
                        cols, dst, rows_pad, kp);
     return TF_CHECK_LAUNCH();
 }

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void shade_forward_kernel(const TfShade S, con
                     for (int k = 0; k < F; ++k) {
                         const float a = v * fr;
                         float sn, cs;
-                        sincosf(a, &sn, &cs);
+                        pe_sincos(a, &sn, &cs);
                         const int cs_i = d * F + k;
                         if (mk) {
                             sn *= mk[cs_i];

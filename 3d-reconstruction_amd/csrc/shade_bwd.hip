@@ -210,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                     float fr = 1.f;
                     for (int k = 0; k < F; ++k) {
                         float sn, cs;
-                        sincosf(v * fr, &sn, &cs);
+                        pe_sincos(v * fr, &sn, &cs);
                         const int ci = d * F + k;
                         if (mk) {
                             sn *= mk[ci];
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         {   // dH1[f1][s] = sum_f2 W2[f2][f1] dZ2[s][f2];  dZ1 = dH1 . [H1 > 0] written in place of H1
             f32x4 acc[1][NSW];
             zero_acc(acc);
-            mma_gen<1, NSW, COL, ROW>(S.w2, kpad16(FC), 16 * my_ft, H2, L.sh, s_base, FC / 16, acc);
+            mma_gen<1, NSW, ROW, ROW>(S.w2t, FC, 16 * my_ft, H2, L.sh, s_base, FC / 16, acc);
             const int f = 16 * my_ft + 4 * lg;
 #pragma unroll
             for (int j = 0; j < NSW; ++j) {
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         for (int kt = wave; kt < kt1; kt += NW) {
             f32x4 acc[1][4];
             zero_acc(acc);
-            mma_gen<1, 4, COL, ROW>(S.w1, kp1, 16 * kt, H1, L.sh, 0, FC / 16, acc);
+            mma_gen<1, 4, ROW, ROW>(S.w1t, FC, 16 * kt, H1, L.sh, 0, FC / 16, acc);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 *reinterpret_cast<f32x4*>(X + (16 * j + lc) * L.sx + 16 * kt + 4 * lg) = acc[0][j];
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                             float fr = 1.f;
                             for (int k = 0; k < F; ++k) {
                                 float sn, cs;
-                                sincosf(v * fr, &sn, &cs);
+                                pe_sincos(v * fr, &sn, &cs);
                                 const int ci = d * F + k;
                                 const float ms = mk ? mk[ci] : 1.f, mc = mk ? mk[D * F + ci] : 1.f;
                                 gsum += dx[off + ci] * (cs * fr * ms);
@@ -591,7 +591,7 @@ int tf_shade_backward(const TfShade* shade, const float* rays, int ndc, const in
     if (bytes > 160 * 1024) return (int)hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;
-    if (!grads->dv_out || !grads->wslab) return (int)hipErrorInvalidValue;
+    if (!grads->dv_out || !grads->wslab || !shade->w1t || !shade->w2t) return (int)hipErrorInvalidValue;
     TileSrc src{counters, seg_cap, 0, app_ray, app_xyz, rays, ndc};
     const int n_wg = 256;
     hipLaunchKernelGGL(fn, dim3(n_wg), dim3(512), bytes, (hipStream_t)stream, *shade, src, grad_rgb, *grads);

@@ -362,19 +362,21 @@ class TensorBase(nn.Module):
             f.alpha_cells = None
         return f
 
-    def _packed(self, key, src, rows_pad):
-        """Zero-padded copy [rows_pad][kpad16(cols)] of a weight matrix, refreshed when it changes."""
+    def _packed(self, key, src, rows_pad, transpose=False):
+        """Zero-padded copy [rows_pad][kpad16(cols)] of a weight matrix (or its transpose
+        [kpad16(cols)][rows_pad]), refreshed when it changes."""
         rows, cols = src.shape
         kp = (cols + 15) // 16 * 16
-        tag = (src.data_ptr(), src._version, rows_pad, kp)
+        tag = (src.data_ptr(), src._version, rows_pad, kp, transpose)
         hit = self._pack_cache.get(key)
         if hit is not None and hit[0] == tag and not torch.cuda.is_current_stream_capturing():
             return hit[1]   # (while a graph is being captured the pack launch must be part of the graph)
-        dst = hit[1] if hit is not None and tuple(hit[1].shape) == (rows_pad, kp) else \
-            torch.empty((rows_pad, kp), dtype=torch.float32, device=src.device)
+        shape = (kp, rows_pad) if transpose else (rows_pad, kp)
+        dst = hit[1] if hit is not None and tuple(hit[1].shape) == shape else \
+            torch.empty(shape, dtype=torch.float32, device=src.device)
         s = src.detach().contiguous()
-        H.check(H.lib().tf_pack_matrix(s.data_ptr(), rows, cols, dst.data_ptr(), rows_pad, _stream()),
-                "tf_pack_matrix")
+        fn = H.lib().tf_pack_matrix_t if transpose else H.lib().tf_pack_matrix
+        H.check(fn(s.data_ptr(), rows, cols, dst.data_ptr(), rows_pad, _stream()), "tf_pack_matrix")
         self._pack_cache[key] = (tag, dst)
         return dst
 
@@ -404,7 +406,7 @@ class TensorBase(nn.Module):
             blocks.append((src, freqs, mv))
         return blocks, keep
 
-    def _shade_desc(self, app_masks, enc_mask, dev):
+    def _shade_desc(self, app_masks, enc_mask, dev, train=False):
         s = H.TfShade()
         s.model = H.MODEL_CP if self._is_cp() else H.MODEL_VM
         s.grid = _i3(self._geom['grid'])
@@ -439,6 +441,11 @@ class TensorBase(nn.Module):
         w1 = self._packed('w1', mlp[0].weight, self.featureC)
         w2 = self._packed('w2', mlp[2].weight, self.featureC)
         keep += [w1, w2]
+        if train:     # the backward GEMMs dH1 = W2^T dZ2, dX = W1^T dZ1 read the transposes
+            w1t = self._packed('w1t', mlp[0].weight, self.featureC, transpose=True)
+            w2t = self._packed('w2t', mlp[2].weight, self.featureC, transpose=True)
+            keep += [w1t, w2t]
+            s.w1t, s.w2t = w1t.data_ptr(), w2t.data_ptr()
         s.w1, s.b1 = w1.data_ptr(), mlp[0].bias.data_ptr()
         s.w2, s.b2 = w2.data_ptr(), mlp[2].bias.data_ptr()
         s.w3, s.b3 = mlp[4].weight.data_ptr(), mlp[4].bias.data_ptr()
@@ -543,7 +550,7 @@ class TensorBase(nn.Module):
         use_bg = bool(white_bg or (is_train and bool(torch.rand((1,)) < 0.5)))
 
         field = self._field_desc(den_masks)
-        shade, keep = self._shade_desc(app_masks, enc_mask, dev)
+        shade, keep = self._shade_desc(app_masks, enc_mask, dev, train=save_valid)
         ws = self._workspace(R, N, dev, save_valid)
         st = _stream()
         ws.counters.zero_()

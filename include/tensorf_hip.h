@@ -137,6 +137,8 @@ typedef struct TfShade {
     const float* b2;
     const float* w3;       /* [3][feature_c] */
     const float* b3;
+    const float* w1t;      /* training only: packed transpose [kpad(in_c)][feature_c] of w1 */
+    const float* w2t;      /* training only: packed transpose [feature_c][feature_c] of w2 */
 } TfShade;
 
 /* kpad(k) = round k up to a multiple of 16 (row stride of every packed matrix = 4 MFMA k-steps). */
@@ -148,6 +150,8 @@ int tf_pack_alpha_cells(const float* volume, int gx, int gy, int gz, uint8_t* ce
 /* Zero-pads a row-major (rows, cols) matrix into (rows_pad, kpad(cols)).  Used for basis_mat and the
  * MLP weights (tensoRF.py:149, mlp.py:34-36). */
 int tf_pack_matrix(const float* src, int rows, int cols, float* dst, int rows_pad, tf_stream_t stream);
+/* dst[c][r] = src[r][c], dst is (kpad(cols), rows_pad) zero padded: the transposes the backward GEMMs read. */
+int tf_pack_matrix_t(const float* src, int rows, int cols, float* dst, int rows_pad, tf_stream_t stream);
 
 /* sample_ray / sample_ray_ndc + bbox test + AlphaGridMask test + compute_densityfeature +
  * feature2density + raw2alpha + app_mask + acc/depth reductions:

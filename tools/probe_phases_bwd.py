@@ -27,7 +27,7 @@ for rep in range(2):
         loss.backward()
     torch.cuda.synchronize()
     lib.tf_debug_phase_cycles_bwd(out, 1)
-names = ["fwd-recompute", "dW3/dZ2 pass", "dW2", "dH1->dZ1", "db1+dW1", "featcopy+dX", "dfeat+dB+dV", "scatter"]
+names = ["fwd-recompute", "dW3/dZ2 pass", "dW2", "dH1->dZ1", "db1+dW1", "featcopy+dX", "dfeat+dB+dV", "dV store"]
 tot = sum(out[i] for i in range(8))
 ntile = sum((int(c) + 63) // 64 for c in model.last["ws"].counters2d[:, 0].tolist())
 print("tiles in last batch", ntile)
