@@ -145,8 +145,11 @@ __global__ __launch_bounds__(256) void shade_forward_kernel(const TfShade S, con
                 const int src_k = S.pe[b].src, F = S.pe[b].freqs;
                 const int D = src_k == TF_SRC_FEAT ? S.app_dim : 3;
                 const float* mk = S.pe[b].mask;
-                for (int it = tid; it < M * D; it += 256) {
-                    const int smp = it / D, d = it % D;
+                // thread -> (sample, dim) without integer division: dims padded to a power of two
+                const int dp = D <= 4 ? 4 : (D <= 32 ? 32 : 64), dsh = D <= 4 ? 2 : (D <= 32 ? 5 : 6);
+                for (int it = tid; it < M * dp; it += 256) {
+                    const int smp = it >> dsh, d = it & (dp - 1);
+                    if (d >= D) continue;
                     float* x = regB + smp * L.sx;
                     const float v = src_k == TF_SRC_FEAT ? x[d] : (src_k == TF_SRC_VIEW ? iview[smp * 3 + d] : ixyz[smp * 3 + d]);
                     float fr = 1.f;

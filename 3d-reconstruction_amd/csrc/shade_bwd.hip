@@ -203,8 +203,11 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                 const int src_k = S.pe[b].src, F = S.pe[b].freqs;
                 const int D = src_k == TF_SRC_FEAT ? S.app_dim : 3;
                 const float* mk = S.pe[b].mask;
-                for (int it = tid; it < M * D; it += NT) {
-                    const int smp = it / D, d = it % D;
+                // thread -> (sample, dim) without integer division: dims padded to a power of two
+                const int dp = D <= 4 ? 4 : (D <= 32 ? 32 : 64), dsh = D <= 4 ? 2 : (D <= 32 ? 5 : 6);
+                for (int it = tid; it < M * dp; it += NT) {
+                    const int smp = it >> dsh, d = it & (dp - 1);
+                    if (d >= D) continue;
                     float* x = X + smp * L.sx;
                     const float v = src_k == TF_SRC_FEAT ? x[d] : (src_k == TF_SRC_VIEW ? iview[smp * 3 + d] : ixyz[smp * 3 + d]);
                     float fr = 1.f;
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         {   // dH1[f1][s] = sum_f2 W2[f2][f1] dZ2[s][f2];  dZ1 = dH1 . [H1 > 0] written in place of H1
             f32x4 acc[1][NSW];
             zero_acc(acc);
-            mma_gen<1, NSW, ROW, ROW>(S.w2t, FC, 16 * my_ft, H2, L.sh, s_base, FC / 16, acc);
+            mma_block<1, NSW>(S.w2t, FC, 16 * my_ft, H2, L.sh, s_base, FC / 16, acc);
             const int f = 16 * my_ft + 4 * lg;
 #pragma unroll
             for (int j = 0; j < NSW; ++j) {
@@ -383,16 +386,14 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         }
         __syncthreads();   // dW1 finished reading X; the H2 region (dZ2) is free
         TF_MARK(4);
-        for (int it = tid; it < M * S.app_dim; it += NT) {   // feat copy for the PE derivative
-            const int smp = it / S.app_dim, d = it % S.app_dim;
-            Fs[smp * L.sf + d] = X[smp * L.sx + d];
-        }
+        for (int smp = wave; smp < M; smp += NW)             // feat copy for the PE derivative
+            if (lane < S.app_dim) Fs[smp * L.sf + lane] = X[smp * L.sx + lane];
         __syncthreads();
         // dX[k][s] = sum_f W1[f][k] dZ1[s][f], written in place of X; wave w owns k tiles w, w+8, ...
         for (int kt = wave; kt < kt1; kt += NW) {
             f32x4 acc[1][4];
             zero_acc(acc);
-            mma_gen<1, 4, ROW, ROW>(S.w1t, FC, 16 * kt, H1, L.sh, 0, FC / 16, acc);
+            mma_block<1, 4>(S.w1t, FC, 16 * kt, H1, L.sh, 0, FC / 16, acc);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 *reinterpret_cast<f32x4*>(X + (16 * j + lc) * L.sx + 16 * kt + 4 * lg) = acc[0][j];
@@ -456,10 +457,9 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         __syncthreads();
         TF_MARK(6);
         // hand dL/dV to the scatter stage (tf_binned_scatter for VM, app_direct_scatter_kernel otherwise)
-        for (int it = tid; it < n * S.n_app_total; it += NT) {
-            const int smp = it / S.n_app_total, c = it % S.n_app_total;
-            G.dv_out[((size_t)s0 + smp) * S.n_app_total + c] = V[smp * L.sv + c];
-        }
+        for (int smp = wave; smp < n; smp += NW)
+            for (int c = lane; c < S.n_app_total; c += 64)
+                G.dv_out[((size_t)s0 + smp) * S.n_app_total + c] = V[smp * L.sv + c];
         first = false;
         __syncthreads();
         TF_MARK(7);
@@ -479,11 +479,15 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
 }
 
 // Sums the workgroups' weight-gradient slabs (fragment order) into the row-major gradient matrices.  Workgroup b
-// wrote its slab iff it owned at least one tile, i.e. b < total tiles.
+// wrote its slab iff it owned at least one tile, i.e. b < total tiles.  One workgroup per 16x16 tile (256 floats
+// = 64 float4 columns): thread (group g = tid>>6, lane) adds the slabs b = g, g+4, ... with 16-B loads, the four
+// groups meet in LDS.
 __global__ __launch_bounds__(256) void wslab_reduce_kernel(const TfShade S, const int* __restrict__ counters,
                                                            int n_wg, const TfShadeGrads G) {
     __shared__ int s_active;
-    if (threadIdx.x == 0) {
+    __shared__ f32x4 part[4][64];
+    const int tid = threadIdx.x, grp = tid >> 6, lane = tid & 63;
+    if (tid == 0) {
         int run = 0;
         for (int g = 0; g < TF_N_SHARDS; ++g) run += (counters[g * TF_SHARD_STRIDE] + M - 1) / M;
         s_active = run < n_wg ? run : n_wg;
@@ -492,20 +496,27 @@ __global__ __launch_bounds__(256) void wslab_reduce_kernel(const TfShade S, cons
     const int active = s_active;
     const int FT = S.feature_c / 16, kt1 = kpad16(S.in_c) / 16, NB = (S.app_dim + 15) / 16, ktB = kpad16(S.n_app_total) / 16;
     const size_t stride = wslab_floats(S);
-    const int total = (FT * FT + FT * kt1 + NB * ktB) * 256;
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
-        float a = 0.f;
-        for (int b = 0; b < active; ++b) a += G.wslab[(size_t)b * stride + q];
-        const int tile = q >> 8, lane = (q >> 2) & 63, e = q & 3;
-        const int r = 4 * (lane >> 4) + e, c = lane & 15;
+    const int tile = blockIdx.x;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    const float* src = G.wslab + (size_t)tile * 256 + lane * 4;
+#pragma unroll 4
+    for (int b = grp; b < active; b += 4) a += *reinterpret_cast<const f32x4*>(src + (size_t)b * stride);
+    part[grp][lane] = a;
+    __syncthreads();
+    if (grp != 0) return;
+    a = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    const int c = lane & 15;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int r = 4 * (lane >> 4) + e;
         if (tile < FT * FT) {
-            G.w2[(size_t)(16 * (tile / FT) + r) * S.feature_c + 16 * (tile % FT) + c] = a;
+            G.w2[(size_t)(16 * (tile / FT) + r) * S.feature_c + 16 * (tile % FT) + c] = a[e];
         } else if (tile < FT * FT + FT * kt1) {
             const int t2 = tile - FT * FT, k = 16 * (t2 % kt1) + c;
-            if (k < S.in_c) G.w1[(size_t)(16 * (t2 / kt1) + r) * S.in_c + k] = a;
+            if (k < S.in_c) G.w1[(size_t)(16 * (t2 / kt1) + r) * S.in_c + k] = a[e];
         } else {
             const int t3 = tile - FT * FT - FT * kt1, f = 16 * (t3 / ktB) + r, cc = 16 * (t3 % ktB) + c;
-            if (f < S.app_dim && cc < S.n_app_total) G.basis[(size_t)f * S.n_app_total + cc] = a;
+            if (f < S.app_dim && cc < S.n_app_total) G.basis[(size_t)f * S.n_app_total + cc] = a[e];
         }
     }
 }
@@ -595,7 +606,8 @@ int tf_shade_backward(const TfShade* shade, const float* rays, int ndc, const in
     TileSrc src{counters, seg_cap, 0, app_ray, app_xyz, rays, ndc};
     const int n_wg = 256;
     hipLaunchKernelGGL(fn, dim3(n_wg), dim3(512), bytes, (hipStream_t)stream, *shade, src, grad_rgb, *grads);
-    hipLaunchKernelGGL(wslab_reduce_kernel, dim3(160), dim3(256), 0, (hipStream_t)stream, *shade, counters, n_wg, *grads);
+    hipLaunchKernelGGL(wslab_reduce_kernel, dim3((unsigned)(wslab_floats(*shade) / 256)), dim3(256), 0, (hipStream_t)stream, *shade,
+                       counters, n_wg, *grads);
     if (grads->direct_scatter)
         hipLaunchKernelGGL(app_direct_scatter_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, *shade, src, *grads);
     return TF_CHECK_LAUNCH();
