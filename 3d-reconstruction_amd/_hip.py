@@ -94,7 +94,8 @@ _SIGS = {
     "tf_march_backward": [C.POINTER(TfField), C.POINTER(TfMarchIO), _fp, _fp, C.c_int, _fp, _fp,
                           C.POINTER(TfFactorGrads), _fp, _fp, _fp],
     "tf_shade_backward_wslab_floats": [C.POINTER(TfShade)],
-    "tf_bin_nkeys": [C.POINTER(C.c_int * 3), C.c_int, C.c_int],
+    "tf_bin_nkeys": [C.POINTER(C.c_int * 3), C.POINTER(C.c_int * 3), C.c_int, C.c_int],
+    "tf_bin_keys_per_entry": [C.POINTER(C.c_int * 3)],
     "tf_binned_scatter": [C.POINTER(TfBinJob), _fp],
     "tf_shade_backward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp,
                           C.POINTER(TfShadeGrads), _fp],

@@ -81,7 +81,8 @@ class _RenderFn(torch.autograd.Function):
         binned = ws.binned_cfg is not None
 
         def bin_job(factors, fgrads, slot, xyz, grad, grad_ld, part):
-            nkeys = ws.binned_cfg[0]
+            nkeys = ws.binned_cfg[0 if part == "density" else 1]
+            nmax = max(ws.binned_cfg[0], ws.binned_cfg[1])
             j = H.TfBinJob()
             j.factors, j.grads = factors, fgrads
             j.grid = c['field'].grid
@@ -89,8 +90,8 @@ class _RenderFn(torch.autograd.Function):
             j.xyz, j.grad, j.grad_ld = xyz.data_ptr(), grad.data_ptr(), grad_ld
             j.tile, j.bucket, j.chunk = model.bin_tile, model.bin_bucket, model.bin_chunk
             ints = ws.bin_ints.data_ptr()
-            j.hist, j.offsets = ints, ints + 4 * (nkeys + 8)
-            j.cursor, j.chunk_off = ints + 8 * (nkeys + 8), ints + 12 * (nkeys + 8)
+            j.hist, j.offsets = ints, ints + 4 * (nmax + 8)
+            j.cursor, j.chunk_off = ints + 8 * (nmax + 8), ints + 12 * (nmax + 8)
             j.binned, j.nkeys = ws.binned.data_ptr(), nkeys
             model._timed("tf_binned_scatter_" + part, lib.tf_binned_scatter, C.byref(j), st)
 

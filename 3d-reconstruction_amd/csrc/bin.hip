@@ -19,29 +19,37 @@ using namespace tf;
 
 namespace {
 
+constexpr int kCG = 16;   // components per key: wide decompositions are split into 16-component groups so that
+                          // one workgroup's private accumulation blocks stay small (occupancy)
+
 struct KeyMap {
     int T, LB;
-    int ntx[3];
+    int ntx[3], ptiles[3], lbuckets[3], ncg[3];
     int plane_base[3], line_base[3];
-    int nkeys;
+    int nkeys, keys_per_entry;
 };
 
-__host__ __device__ inline KeyMap make_keymap(const int grid[3], int T, int LB) {
+__host__ __device__ inline KeyMap make_keymap(const int grid[3], const int n_comp[3], int T, int LB) {
     KeyMap K;
     K.T = T;
     K.LB = LB;
-    int run = 0;
+    int run = 0, kpe = 0;
     for (int i = 0; i < 3; ++i) {
         const int W = grid[i == 2 ? 1 : 0], H = grid[i == 0 ? 1 : 2];
+        K.ncg[i] = (n_comp[i] + kCG - 1) / kCG;
         K.ntx[i] = (W + T - 1) / T;
+        K.ptiles[i] = K.ntx[i] * ((H + T - 1) / T);
         K.plane_base[i] = run;
-        run += K.ntx[i] * ((H + T - 1) / T);
+        run += K.ptiles[i] * K.ncg[i];
+        kpe += 2 * K.ncg[i];
     }
     for (int i = 0; i < 3; ++i) {
+        K.lbuckets[i] = (grid[2 - i] + LB - 1) / LB;
         K.line_base[i] = run;
-        run += (grid[2 - i] + LB - 1) / LB;
+        run += K.lbuckets[i] * K.ncg[i];
     }
     K.nkeys = run;
+    K.keys_per_entry = kpe;
     return K;
 }
 
@@ -59,6 +67,7 @@ __device__ __forceinline__ void sample_geom(const int grid[3], const float u[3],
     }
 }
 
+// keys of channel group 0: keys[i] (plane i) and keys[3+i] (line i); group g adds g*ptiles[i] / g*lbuckets[i]
 __device__ __forceinline__ void sample_keys(const KeyMap& K, const int grid[3], const SampleGeom& g, int keys[6]) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -68,6 +77,12 @@ __device__ __forceinline__ void sample_keys(const KeyMap& K, const int grid[3], 
         keys[3 + i] = K.line_base[i] + l / K.LB;
     }
 }
+#define TF_FOR_EACH_KEY(K, keys, key, BODY)                                   \
+    _Pragma("unroll") for (int _i = 0; _i < 3; ++_i)                          \
+        for (int _g = 0; _g < (K).ncg[_i]; ++_g) {                            \
+            { const int key = (keys)[_i] + _g * (K).ptiles[_i]; BODY; }       \
+            { const int key = (keys)[3 + _i] + _g * (K).lbuckets[_i]; BODY; } \
+        }
 
 constexpr int kSlices = 8;   // workgroups per entry shard in the count / fill passes
 
@@ -91,8 +106,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(const TfBinJob J, const 
         sample_geom(J.grid, u, sg);
         int keys[6];
         sample_keys(K, J.grid, sg, keys);
-#pragma unroll
-        for (int q = 0; q < 6; ++q) atomicAdd(&lh[keys[q]], 1);
+        TF_FOR_EACH_KEY(K, keys, key, atomicAdd(&lh[key], 1));
     }
     __syncthreads();
     for (int i = threadIdx.x; i < K.nkeys; i += 256)
@@ -156,8 +170,7 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(const TfBinJob J, const K
         sample_geom(J.grid, u, sg);
         int keys[6];
         sample_keys(K, J.grid, sg, keys);
-#pragma unroll
-        for (int q = 0; q < 6; ++q) atomicAdd(&lh[keys[q]], 1);
+        TF_FOR_EACH_KEY(K, keys, key, atomicAdd(&lh[key], 1));
     }
     __syncthreads();
     for (int i = threadIdx.x; i < K.nkeys; i += 256) {
@@ -172,8 +185,7 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(const TfBinJob J, const K
         sample_geom(J.grid, u, sg);
         int keys[6];
         sample_keys(K, J.grid, sg, keys);
-#pragma unroll
-        for (int q = 0; q < 6; ++q) J.binned[lb[keys[q]] + atomicAdd(&lh[keys[q]], 1)] = (int)e;
+        TF_FOR_EACH_KEY(K, keys, key, J.binned[lb[key] + atomicAdd(&lh[key], 1)] = (int)e);
     }
 }
 
@@ -212,24 +224,29 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const TfBinJob J, cons
         const int key = J.chunk_off[K.nkeys + 1 + w], chunk = w - J.chunk_off[key];
         const int beg = J.offsets[key] + chunk * J.chunk, end = min(J.offsets[key + 1], beg + J.chunk);
         const bool is_line = key >= K.line_base[0];
-        int i = 0;
+        int i = 0, local = 0, cg = 0;
         if (is_line) {
             i = key >= K.line_base[2] ? 2 : (key >= K.line_base[1] ? 1 : 0);
+            cg = (key - K.line_base[i]) / K.lbuckets[i];
+            local = (key - K.line_base[i]) - cg * K.lbuckets[i];
         } else {
             i = key >= K.plane_base[2] ? 2 : (key >= K.plane_base[1] ? 1 : 0);
+            cg = (key - K.plane_base[i]) / K.ptiles[i];
+            local = (key - K.plane_base[i]) - cg * K.ptiles[i];
         }
-        const int C = J.factors.n_comp[i];
-        int coff = 0;
+        const int CF = J.factors.n_comp[i];           // components of the factor tensor (memory stride)
+        const int c0 = cg * kCG, C = min(kCG, CF - c0); // this key covers components [c0, c0 + C)
+        int coff = c0;
         for (int q = 0; q < i; ++q) coff += J.factors.n_comp[q];
-        const float* mk = J.factors.mask[i];
+        const float* mk = J.factors.mask[i] ? J.factors.mask[i] + c0 : nullptr;
         const int T1 = K.T + 1;
         const int nblk = is_line ? (K.LB + 1) * C : T1 * T1 * C;
         for (int q = tid; q < 4 * nblk; q += 256) blk0[q] = 0.f;
         float* blk = blk0 + wave * nblk;
         const int W = J.grid[mat0(i)], Hh = J.grid[mat1(i)], Gl = J.grid[vecm(i)];
-        const int t = key - K.plane_base[i], tyb = is_line ? 0 : (t / K.ntx[i]) * K.T, txb = is_line ? 0 : (t % K.ntx[i]) * K.T;
-        const int lb0 = is_line ? (key - K.line_base[i]) * K.LB : 0;
-        const bool vec = (C & 3) == 0 && (coff & 3) == 0 && (J.grad_ld & 3) == 0;
+        const int tyb = is_line ? 0 : (local / K.ntx[i]) * K.T, txb = is_line ? 0 : (local % K.ntx[i]) * K.T;
+        const int lb0 = is_line ? local * K.LB : 0;
+        const bool vec = (C & 3) == 0 && (CF & 3) == 0 && (coff & 3) == 0 && (J.grad_ld & 3) == 0;
         const int rounds = (end - beg + 4 * ER - 1) / (4 * ER);
         TF_MARK(0);
         for (int rd = 0; rd < rounds; ++rd) {
@@ -267,7 +284,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const TfBinJob J, cons
                 float* dst = pre + ent * C;
                 if (vec) {
                     for (int c = 4 * sub; c < C; c += 4 * LPE) {
-                        float4_t v = is_line ? bilerp4(J.factors.plane[i], C, tp, c) : lerp4(J.factors.line[i], C, tl, c);
+                        float4_t v = is_line ? bilerp4(J.factors.plane[i], CF, tp, c0 + c) : lerp4(J.factors.line[i], CF, tl, c0 + c);
                         v *= grow ? ld4(grow + c) : (float4_t){df, df, df, df};
                         if (mk) {
                             const float4_t m = ld4(mk + c);
@@ -277,7 +294,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const TfBinJob J, cons
                     }
                 } else {
                     for (int c = sub; c < C; c += LPE) {
-                        float v = is_line ? bilerp1(J.factors.plane[i], C, tp, c) : lerp1(J.factors.line[i], C, tl, c);
+                        float v = is_line ? bilerp1(J.factors.plane[i], CF, tp, c0 + c) : lerp1(J.factors.line[i], CF, tl, c0 + c);
                         v *= grow ? grow[c] : df;
                         if (mk) v *= mk[c] * mk[c];
                         dst[c] = v;
@@ -312,7 +329,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const TfBinJob J, cons
                 const float v = (blk0[q] + blk0[nblk + q]) + (blk0[2 * nblk + q] + blk0[3 * nblk + q]);
                 if (v == 0.f) continue;
                 const int c = q % C, cell = q / C, yy = tyb + cell / T1, xx = txb + cell % T1;
-                if (yy < Hh && xx < W) atomicAdd(gp + ((size_t)yy * W + xx) * C + c, v);
+                if (yy < Hh && xx < W) atomicAdd(gp + ((size_t)yy * W + xx) * CF + c0 + c, v);
             }
         } else {
             float* gl = J.grads.line[i] + rep;
@@ -320,7 +337,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const TfBinJob J, cons
                 const float v = (blk0[q] + blk0[nblk + q]) + (blk0[2 * nblk + q] + blk0[3 * nblk + q]);
                 if (v == 0.f) continue;
                 const int c = q % C, ent = lb0 + q / C;
-                if (ent < Gl) atomicAdd(gl + (size_t)ent * C + c, v);
+                if (ent < Gl) atomicAdd(gl + (size_t)ent * CF + c0 + c, v);
             }
         }
         __syncthreads();
@@ -344,14 +361,22 @@ int tf_debug_phase_cycles_bin(unsigned long long* out16, int reset) {
 }
 #endif
 
-int tf_bin_nkeys(const int grid[3], int tile, int bucket) { return make_keymap(grid, tile, bucket).nkeys; }
+int tf_bin_nkeys(const int grid[3], const int n_comp[3], int tile, int bucket) {
+    return make_keymap(grid, n_comp, tile, bucket).nkeys;
+}
+int tf_bin_keys_per_entry(const int n_comp[3]) {
+    int k = 0;
+    for (int i = 0; i < 3; ++i) k += 2 * ((n_comp[i] + kCG - 1) / kCG);
+    return k;
+}
 
 int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
-    const KeyMap K = make_keymap(job->grid, job->tile, job->bucket);
-    if (K.nkeys != job->nkeys || K.nkeys > 12000) return (int)hipErrorInvalidValue;
+    const KeyMap K = make_keymap(job->grid, job->factors.n_comp, job->tile, job->bucket);
+    if (K.nkeys != job->nkeys || K.nkeys > 18000) return (int)hipErrorInvalidValue;   // 2 LDS ints per key in K3
     int cmax = job->factors.n_comp[0];
     for (int i = 1; i < 3; ++i) cmax = job->factors.n_comp[i] > cmax ? job->factors.n_comp[i] : cmax;
+    cmax = cmax > kCG ? kCG : cmax;
     const size_t blk_bytes = (size_t)(job->tile + 1) * (job->tile + 1) * cmax * 4;
     const size_t lblk_bytes = (size_t)(job->bucket + 1) * cmax * 4;
     const int ER = entries_per_round(cmax);
@@ -361,6 +386,9 @@ int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream) {
     per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
     hipError_t e = hipSuccess;
     hipLaunchKernelGGL(zero_ints_kernel, dim3((K.nkeys + 255) / 256), dim3(256), 0, st, job->hist, K.nkeys);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(int) * K.nkeys));
+    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(bin_count_kernel, dim3(TF_N_SHARDS * kSlices), dim3(256), sizeof(int) * K.nkeys, st, *job, K);
     hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, *job, K.nkeys);
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -156,10 +156,10 @@ class _Workspace:
             n_app, wslab = train_extra
             spec += [("dv", cap * n_app, torch.float32), ("wslab", wslab, torch.float32)]
             if binned is not None:   # binned gradient scatter (csrc/bin.hip): entry lists + sort workspace
-                nkeys = binned[0]
+                nkeys, kpe = max(binned[0], binned[1]), binned[2]
                 spec += [("ent_xyz", cap * 3, torch.float32), ("ent_df", cap, torch.float32),
-                         ("binned", 6 * cap, torch.int32),
-                         ("bin_ints", 5 * (nkeys + 8) + 6 * cap // 256 + 64, torch.int32)]
+                         ("binned", kpe * cap, torch.int32),
+                         ("bin_ints", 5 * (nkeys + 8) + kpe * cap // 256 + 64, torch.int32)]
         if debug:
             spec += [("dbg_bbox", R * words * 2, torch.int32), ("dbg_valid", R * words * 2, torch.int32),
                      ("dbg_app", R * words * 2, torch.int32)]
@@ -498,7 +498,11 @@ class TensorBase(nn.Module):
             binned = None
             if save_valid and not self._is_cp() and self.binned_scatter:
                 g3 = (C.c_int * 3)(*self._geom['grid'])
-                binned = (int(H.lib().tf_bin_nkeys(C.byref(g3), self.bin_tile, self.bin_bucket)), self._n_app_total())
+                cd, ca = (C.c_int * 3)(*self.density_n_comp), (C.c_int * 3)(*self.app_n_comp)
+                lib = H.lib()
+                binned = (int(lib.tf_bin_nkeys(C.byref(g3), C.byref(cd), self.bin_tile, self.bin_bucket)),
+                          int(lib.tf_bin_nkeys(C.byref(g3), C.byref(ca), self.bin_tile, self.bin_bucket)),
+                          max(int(lib.tf_bin_keys_per_entry(C.byref(cd))), int(lib.tf_bin_keys_per_entry(C.byref(ca)))))
             extra = None
             if save_valid:
                 sh, _keep = self._shade_desc([None, None, None], None, dev)

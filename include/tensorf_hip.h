@@ -221,12 +221,14 @@ typedef struct TfBinJob {
     int grad_ld;              /* 0: one scalar per entry, broadcast over components; else row stride */
     int tile, bucket, chunk;  /* T, LB, max entries per workgroup */
     /* workspace (ints): hist[nkeys], offsets[nkeys+1], cursor[nkeys], chunk_off[nkeys+1] followed by the
-     * work-item table (nkeys + 6*entries/chunk ints); binned[6*entries] */
+     * work-item table (nkeys + kpe*entries/chunk ints); binned[kpe*entries], kpe = tf_bin_keys_per_entry */
     int* hist; int* offsets; int* cursor; int* chunk_off; int* binned;
     int nkeys;
 } TfBinJob;
-/* number of keys a job needs for (grid, T, LB): 3 plane tile maps followed by 3 line bucket maps */
-int tf_bin_nkeys(const int grid[3], int tile, int bucket);
+/* Decompositions wider than 16 components are split into 16-component groups, each with its own key, so the
+ * per-workgroup LDS blocks stay small.  Number of keys for (grid, n_comp, T, LB), and keys emitted per entry: */
+int tf_bin_nkeys(const int grid[3], const int n_comp[3], int tile, int bucket);
+int tf_bin_keys_per_entry(const int n_comp[3]);
 int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream);
 
 /* dst[j] = sum_r rep[r*stride + j], j < numel: folds the line-gradient replicas. */
