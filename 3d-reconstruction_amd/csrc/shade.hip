@@ -42,9 +42,18 @@ __global__ __launch_bounds__(256) void shade_forward_kernel(const TfShade S, con
     }
 
     TF_T0();
-    for (int t = blockIdx.x;; t += gridDim.x) {
+    // Tiles are handed out dynamically (one returning atomic per tile on a per-launch ticket word, fetched one
+    // tile ahead): with ~2.5 tiles per resident workgroup a static stride would leave half the chip idle for the
+    // third round.  Direct mode (point lists) keeps the static stride.
+    int* ticket = src.counters ? const_cast<int*>(src.counters) + TF_TICKET_SLOT : nullptr;
+    int* tbox = reinterpret_cast<int*>(lds + L.offPre) + TF_N_SHARDS + 2;
+    if (ticket && tid == 0) tbox[0] = atomicAdd(ticket, 1);
+    __syncthreads();
+    for (int t = ticket ? tbox[0] : (int)blockIdx.x;; t = ticket ? tbox[0] : t + (int)gridDim.x) {
         int s0, n;
         if (!locate_tile(src, pre, t, s0, n)) break;
+        __syncthreads();                                   // everyone has read tbox[0]
+        if (ticket && tid == 0) tbox[0] = atomicAdd(ticket, 1);   // next tile, resolved while this one is shaded
         TF_MARK(7);
 
         // ---- tile info

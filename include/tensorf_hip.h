@@ -37,6 +37,7 @@ typedef void* tf_stream_t; /* hipStream_t */
 #define TF_SHARD_STRIDE 32
 #define TF_MAX_SAMPLES 8192   /* samples per ray handled by one LDS queue */
 #define TF_TILE 64            /* shaded samples per shading tile */
+#define TF_TICKET_SLOT 4      /* counters[4]: tile ticket of tf_shade_forward (zeroed with the counters) */
 
 enum { TF_MODEL_VM = 0, TF_MODEL_CP = 1 };
 enum { TF_ACT_SOFTPLUS = 0, TF_ACT_RELU = 1 };
