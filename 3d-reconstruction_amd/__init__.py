@@ -3,9 +3,10 @@ from . import _hip
 from .field import (AlphaGridMask, MLPRender, MLPRender_Fea, MLPRender_PE, TensorBase, TensorCP, TensorVMSplit,
                     channel_last_param, is_channel_last)
 from .graph import GraphedTrainStep
+from .regularizers import TVLoss
 from .renderer import OctreeRender_trilinear_fast
 from .utils import N_to_reso, cal_n_samples, get_free_mask
 
 __all__ = ["AlphaGridMask", "MLPRender", "MLPRender_Fea", "MLPRender_PE", "TensorBase", "TensorCP",
            "TensorVMSplit", "OctreeRender_trilinear_fast", "N_to_reso", "cal_n_samples", "get_free_mask",
-           "channel_last_param", "is_channel_last", "GraphedTrainStep", "_hip"]
+           "channel_last_param", "is_channel_last", "GraphedTrainStep", "TVLoss", "_hip"]

@@ -90,6 +90,10 @@ _SIGS = {
     "tf_composite_forward": [C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp],
     "tf_density_points": [C.POINTER(TfField), _fp, C.c_int, _fp, _fp],
     "tf_appfeature_points": [C.POINTER(TfShade), _fp, C.c_int, _fp, _fp],
+    "tf_alpha_points": [C.POINTER(TfField), _fp, C.c_int, C.c_float, _fp, _fp],
+    "tf_sample_alpha_points": [_fp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3), _fp,
+                               C.c_int, _fp, _fp],
+    "tf_filter_rays": [C.POINTER(TfField), _fp, C.c_int, C.c_int, C.c_int, _fp, _fp],
     "tf_reduce_replicas": [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp],
     "tf_march_backward": [C.POINTER(TfField), C.POINTER(TfMarchIO), _fp, _fp, C.c_int, _fp, _fp,
                           C.POINTER(TfFactorGrads), _fp, _fp, _fp],

@@ -96,6 +96,21 @@ class AlphaGridMask(nn.Module):
             self._cells = cells
         return self._cells
 
+    def sample_alpha(self, xyz_sampled):
+        """models/tensorBase.py:41-45: trilinear lookup of the alpha volume at world-space points -> (S,)."""
+        vol = self.alpha_volume.contiguous().float()
+        if not vol.is_cuda:
+            raise H.HipError("AlphaGridMask.sample_alpha needs the volume on the GPU")
+        xyz = xyz_sampled.detach().reshape(-1, 3).to(torch.float32).contiguous()
+        gz, gy, gx = vol.shape[-3:]
+        if getattr(self, '_host', None) is None:
+            self._host = dict(grid=self.gridSize.tolist(), lo=self.aabb[0].tolist(), inv=self.invgridSize.tolist())
+        out = torch.empty(xyz.shape[0], dtype=torch.float32, device=xyz.device)
+        lo, inv = _f3(self._host['lo']), _f3(self._host['inv'])
+        H.check(H.lib().tf_sample_alpha_points(vol.data_ptr(), gx, gy, gz, C.byref(lo), C.byref(inv), xyz.data_ptr(),
+                                               xyz.shape[0], out.data_ptr(), _stream()), "tf_sample_alpha_points")
+        return out
+
     def normalize_coord(self, xyz_sampled):
         return (xyz_sampled - self.aabb[0]) * self.invgridSize - 1
 
@@ -252,6 +267,7 @@ class TensorBase(nn.Module):
         self.aabbDiag = torch.sqrt(torch.sum(torch.square(self.aabbSize)))
         self.nSamples = int((self.aabbDiag / self.stepSize).item()) + 1
         self._geom = None
+        self._ws_cache, self._train_ws, self._named_cache = {}, {}, None   # sized for the previous grid
 
     def init_svd_volume(self, res, device):
         pass
@@ -622,6 +638,71 @@ class TensorBase(nn.Module):
                 "tf_appfeature_points")
         return out
 
+    # ---- alpha-volume rebuild / ray filtering ----------------------------------
+    def compute_alpha(self, xyz_locs, mask, length=1):
+        """models/tensorBase.py:298-318 as one fused kernel (alpha-mask test, density lookup, activation,
+        1 - exp(-sigma*length)) on world-space points."""
+        dev = xyz_locs.device
+        shape = xyz_locs.shape[:-1]
+        field = self._field_desc(self._decomp_mask_vectors(mask, self.density_n_comp, dev))
+        xyz = xyz_locs.detach().reshape(-1, 3).to(torch.float32).contiguous()
+        out = torch.empty(xyz.shape[0], dtype=torch.float32, device=dev)
+        H.check(H.lib().tf_alpha_points(C.byref(field), xyz.data_ptr(), xyz.shape[0], float(length), out.data_ptr(),
+                                        _stream()), "tf_alpha_points")
+        return out.view(shape)
+
+    @torch.no_grad()
+    def getDenseAlpha(self, gridSize=None, mask=None):
+        """models/tensorBase.py:215-230 (one kernel call over the whole lattice instead of one per x-slice)."""
+        gridSize = self.gridSize if gridSize is None else gridSize
+        samples = torch.stack(torch.meshgrid(
+            torch.linspace(0, 1, int(gridSize[0])),
+            torch.linspace(0, 1, int(gridSize[1])),
+            torch.linspace(0, 1, int(gridSize[2])), indexing='ij'), -1).to(self.device)
+        dense_xyz = self.aabb[0] * (1 - samples) + self.aabb[1] * samples
+        alpha = self.compute_alpha(dense_xyz.view(-1, 3), mask, self.stepSize).view(dense_xyz.shape[:-1])
+        return alpha, dense_xyz
+
+    @torch.no_grad()
+    def updateAlphaMask(self, gridSize=(200, 200, 200), mask=None):
+        """models/tensorBase.py:233-256."""
+        alpha, dense_xyz = self.getDenseAlpha(gridSize, mask)
+        dense_xyz = dense_xyz.transpose(0, 2).contiguous()
+        alpha = alpha.clamp(0, 1).transpose(0, 2).contiguous()[None, None]
+        total_voxels = gridSize[0] * gridSize[1] * gridSize[2]
+        ks = 3
+        alpha = torch.nn.functional.max_pool3d(alpha, kernel_size=ks, padding=ks // 2, stride=1).view(list(gridSize)[::-1])
+        alpha[alpha >= self.alphaMask_thres] = 1
+        alpha[alpha < self.alphaMask_thres] = 0
+        self.alphaMask = AlphaGridMask(self.device, self.aabb, alpha)
+        valid_xyz = dense_xyz[alpha > 0.5]
+        xyz_min = valid_xyz.amin(0)
+        xyz_max = valid_xyz.amax(0)
+        new_aabb = torch.stack((xyz_min, xyz_max))
+        total = torch.sum(alpha)
+        print(f"bbox: {xyz_min, xyz_max} alpha rest %%%f" % (total / total_voxels * 100))
+        return new_aabb
+
+    @torch.no_grad()
+    def filtering_rays(self, all_rays, all_rgbs, N_samples=256, chunk=10240 * 5, bbox_only=False):
+        """models/tensorBase.py:259-288 (the predicate runs in tf_filter_rays, `chunk` only bounds the staging)."""
+        N = int(torch.tensor(all_rays.shape[:-1]).prod())
+        rays_flat = all_rays.reshape(-1, all_rays.shape[-1])
+        if not bbox_only and self.alphaMask is None:
+            raise ValueError("filtering_rays(bbox_only=False) needs an alphaMask")
+        field = self._field_desc([None, None, None])
+        step = max(int(chunk), 1 << 20)
+        parts = []
+        for s0 in range(0, N, step):
+            rc = rays_flat[s0:s0 + step].to(self.device, torch.float32).contiguous()
+            keep = torch.empty(rc.shape[0], dtype=torch.uint8, device=rc.device)
+            H.check(H.lib().tf_filter_rays(C.byref(field), rc.data_ptr(), rc.shape[0], int(bool(bbox_only)),
+                                           int(N_samples), keep.data_ptr(), _stream()), "tf_filter_rays")
+            parts.append(keep.bool().to(all_rays.device))
+        mask_filtered = torch.cat(parts).view(all_rgbs.shape[:-1])
+        print(f'Ray filtering done! ray mask ratio: {torch.sum(mask_filtered) / N}')
+        return all_rays[mask_filtered], all_rgbs[mask_filtered]
+
     def feature2density(self, density_features):
         """models/tensorBase.py:291-295 (elementwise; used by callers outside the fused path)."""
         if self.fea2denseAct == "softplus":
@@ -671,6 +752,84 @@ class TensorVMSplit(TensorBase):
         return grad_vars
 
 
+    # ---- regularisers on the factor tensors (models/tensoRF.py:175-205; SURVEY row f-3, torch ops for now) ----
+    def vectorDiffs(self, vector_comps):
+        total = 0
+        for idx in range(len(vector_comps)):
+            n_comp, n_size = vector_comps[idx].shape[1:-1]
+            v = vector_comps[idx].reshape(n_comp, n_size)
+            dotp = torch.matmul(v, v.transpose(-1, -2))
+            non_diagonal = dotp.view(-1)[1:].view(n_comp - 1, n_comp + 1)[..., :-1]
+            total = total + torch.mean(torch.abs(non_diagonal))
+        return total
+
+    def vector_comp_diffs(self):
+        return self.vectorDiffs(self.density_line) + self.vectorDiffs(self.app_line)
+
+    def density_L1(self):
+        total = 0
+        for idx in range(len(self.density_plane)):
+            total = total + torch.mean(torch.abs(self.density_plane[idx])) + torch.mean(torch.abs(self.density_line[idx]))
+        return total
+
+    def TV_loss_density(self, reg):
+        total = 0
+        for idx in range(len(self.density_plane)):
+            total = total + reg(self.density_plane[idx]) * 1e-2
+        return total
+
+    def TV_loss_app(self, reg):
+        total = 0
+        for idx in range(len(self.app_plane)):
+            total = total + reg(self.app_plane[idx]) * 1e-2
+        return total
+
+    # ---- coarse-to-fine schedule (models/tensoRF.py:267-327; torch resize / crop, channel-last storage kept) ----
+    @torch.no_grad()
+    def up_sampling_VM(self, plane_coef, line_coef, res_target):
+        for i in range(len(self.vecMode)):
+            vec_id = self.vecMode[i]
+            mat_id_0, mat_id_1 = self.matMode[i]
+            plane_coef[i] = channel_last_param(torch.nn.functional.interpolate(
+                plane_coef[i].data, size=(int(res_target[mat_id_1]), int(res_target[mat_id_0])), mode='bilinear',
+                align_corners=True))
+            line_coef[i] = channel_last_param(torch.nn.functional.interpolate(
+                line_coef[i].data, size=(int(res_target[vec_id]), 1), mode='bilinear', align_corners=True))
+        return plane_coef, line_coef
+
+    @torch.no_grad()
+    def upsample_volume_grid(self, res_target):
+        self.app_plane, self.app_line = self.up_sampling_VM(self.app_plane, self.app_line, res_target)
+        self.density_plane, self.density_line = self.up_sampling_VM(self.density_plane, self.density_line, res_target)
+        self.update_stepSize(res_target)
+        print(f'upsamping to {res_target}')
+
+    @torch.no_grad()
+    def shrink(self, new_aabb):
+        xyz_min, xyz_max = new_aabb
+        t_l, b_r = (xyz_min - self.aabb[0]) / self.units, (xyz_max - self.aabb[0]) / self.units
+        t_l, b_r = torch.round(torch.round(t_l)).long(), torch.round(b_r).long() + 1
+        b_r = torch.stack([b_r, self.gridSize]).amin(0)
+        for i in range(len(self.vecMode)):
+            mode0 = self.vecMode[i]
+            self.density_line[i] = channel_last_param(self.density_line[i].data[..., t_l[mode0]:b_r[mode0], :])
+            self.app_line[i] = channel_last_param(self.app_line[i].data[..., t_l[mode0]:b_r[mode0], :])
+            mode0, mode1 = self.matMode[i]
+            self.density_plane[i] = channel_last_param(
+                self.density_plane[i].data[..., t_l[mode1]:b_r[mode1], t_l[mode0]:b_r[mode0]])
+            self.app_plane[i] = channel_last_param(
+                self.app_plane[i].data[..., t_l[mode1]:b_r[mode1], t_l[mode0]:b_r[mode0]])
+        if not torch.all(self.alphaMask.gridSize == self.gridSize):
+            t_l_r, b_r_r = t_l / (self.gridSize - 1), (b_r - 1) / (self.gridSize - 1)
+            correct_aabb = torch.zeros_like(new_aabb)
+            correct_aabb[0] = (1 - t_l_r) * self.aabb[0] + t_l_r * self.aabb[1]
+            correct_aabb[1] = (1 - b_r_r) * self.aabb[0] + b_r_r * self.aabb[1]
+            new_aabb = correct_aabb
+        newSize = b_r - t_l
+        self.aabb = new_aabb
+        self.update_stepSize((newSize[0], newSize[1], newSize[2]))
+
+
 class TensorCP(TensorBase):
     """models/tensoRF.py:330-484.  The reference's constructor forwards `device` into `near_far`
     (SURVEY warning 3); keyword `near_far` / `device` are accepted here so train.py's call works."""
@@ -704,3 +863,53 @@ class TensorCP(TensorBase):
         if isinstance(self.renderModule, nn.Module):
             grad_vars += [{'params': self.renderModule.parameters(), 'lr': lr_init_network}]
         return grad_vars
+
+    def density_L1(self):
+        total = 0
+        for idx in range(len(self.density_line)):
+            total = total + torch.mean(torch.abs(self.density_line[idx]))
+        return total
+
+    def TV_loss_density(self, reg):
+        total = 0
+        for idx in range(len(self.density_line)):
+            total = total + reg(self.density_line[idx]) * 1e-3
+        return total
+
+    def TV_loss_app(self, reg):
+        total = 0
+        for idx in range(len(self.app_line)):
+            total = total + reg(self.app_line[idx]) * 1e-3
+        return total
+
+    @torch.no_grad()
+    def upsample_volume_grid(self, res_target):
+        """models/tensoRF.py:418-435."""
+        for i in range(len(self.vecMode)):
+            vec_id = self.vecMode[i]
+            for lines in (self.density_line, self.app_line):
+                lines[i] = channel_last_param(torch.nn.functional.interpolate(
+                    lines[i].data, size=(int(res_target[vec_id]), 1), mode='bilinear', align_corners=True))
+        self.update_stepSize(res_target)
+        print(f'upsamping to {res_target}')
+
+    @torch.no_grad()
+    def shrink(self, new_aabb):
+        """models/tensoRF.py:437-466."""
+        xyz_min, xyz_max = new_aabb
+        t_l, b_r = (xyz_min - self.aabb[0]) / self.units, (xyz_max - self.aabb[0]) / self.units
+        t_l, b_r = torch.round(torch.round(t_l)).long(), torch.round(b_r).long() + 1
+        b_r = torch.stack([b_r, self.gridSize]).amin(0)
+        for i in range(len(self.vecMode)):
+            mode0 = self.vecMode[i]
+            self.density_line[i] = channel_last_param(self.density_line[i].data[..., t_l[mode0]:b_r[mode0], :])
+            self.app_line[i] = channel_last_param(self.app_line[i].data[..., t_l[mode0]:b_r[mode0], :])
+        if not torch.all(self.alphaMask.gridSize == self.gridSize):
+            t_l_r, b_r_r = t_l / (self.gridSize - 1), (b_r - 1) / (self.gridSize - 1)
+            correct_aabb = torch.zeros_like(new_aabb)
+            correct_aabb[0] = (1 - t_l_r) * self.aabb[0] + t_l_r * self.aabb[1]
+            correct_aabb[1] = (1 - b_r_r) * self.aabb[0] + b_r_r * self.aabb[1]
+            new_aabb = correct_aabb
+        newSize = b_r - t_l
+        self.aabb = new_aabb
+        self.update_stepSize((newSize[0], newSize[1], newSize[2]))

@@ -202,6 +202,19 @@ int tf_shade_backward(const TfShade* shade, const float* rays, int ndc, const in
                       const int* app_ray, const float* app_xyz, const float* grad_rgb, const TfShadeGrads* grads,
                       tf_stream_t stream);
 
+/* ---- callers of the density lookup outside the per-ray march ---- */
+/* compute_alpha on world-space points: alpha mask test, normalise, density, activation, 1-exp(-sigma*length).
+ * tensorBase.py:298-318 (used by getDenseAlpha / updateAlphaMask :215-256). */
+int tf_alpha_points(const TfField* field, const float* xyz, int n, float length, float* out_alpha, tf_stream_t stream);
+/* AlphaGridMask.sample_alpha: trilinear grid_sample of the float volume (Gz,Gy,Gx), align_corners, zero padding;
+ * lo / inv = the mask's aabb[0] and 2/aabbSize.  tensorBase.py:41-48. */
+int tf_sample_alpha_points(const float* volume, int gx, int gy, int gz, const float lo[3], const float inv[3],
+                           const float* xyz, int n, float* out, tf_stream_t stream);
+/* filtering_rays: keep[r] = slab test t_max > t_min (bbox_only) or "any of the N eval samples hits the alpha
+ * mask".  tensorBase.py:259-288. */
+int tf_filter_rays(const TfField* field, const float* rays, int n_rays, int bbox_only, int n_samples, uint8_t* keep,
+                   tf_stream_t stream);
+
 /* Binned ("owner computes") scatter of the VM factor gradients — the backward of the plane x line lookups
  * (autograd of tensoRF.py:216-225 / :240-260) without one global atomic per tap.
  * Global float atomics on random 64-B pieces are request-bound (~0.4 TB/s measured), so the samples are first

@@ -289,6 +289,57 @@ def main():
                         bases=eval_sh_bases(2, dirs).numpy())
     print("sh_head done")
 
+    # 8b: lifecycle row f-1 (compute_alpha, sample_alpha, updateAlphaMask, filtering_rays, shrink, upsample) and
+    # the regularisers, all through the reference's own methods
+    torch.manual_seed(6)
+    ml = quiet(TensorVMSplit, base_args(density_n_comp=[8, 8, 8], app_n_comp=[16, 16, 16], featureC=64), cube,
+               [32, 32, 32], [2.0, 6.0], "cpu")
+    trained_like_vm(ml, ball_res=(24, 24, 24), radius=0.9, den_boost=(4.0, 3.0))
+    rec = {"state0/" + k: v.numpy().copy() for k, v in ml.state_dict().items() if not k.startswith("alphaMask")}
+    rec["alpha0"] = ml.alphaMask.alpha_volume[0, 0].numpy().astype(np.uint8)
+    g = torch.Generator().manual_seed(91)
+    pts = (torch.rand(600, 3, generator=g) * 2 - 1) * 1.6
+    with torch.no_grad():
+        rec["pts"] = pts.numpy()
+        rec["sample_alpha"] = ml.alphaMask.sample_alpha(pts).numpy()
+        rec["compute_alpha"] = ml.compute_alpha(pts, None, ml.stepSize).numpy()
+        rec["reg/vector_comp_diffs"] = np.float32(ml.vector_comp_diffs().item())
+        rec["reg/density_L1"] = np.float32(ml.density_L1().item())
+        frays = outside_rays(400, 92, spread=2.5)
+        idx = torch.arange(400).float()[:, None]
+        _, kept = quiet(ml.filtering_rays, frays, idx, bbox_only=True)
+        rec["frays"] = frays.numpy()
+        rec["filter_bbox_kept"] = kept.view(-1).long().numpy()
+        _, kept = quiet(ml.filtering_rays, frays, idx, N_samples=64)
+        rec["filter_alpha_kept"] = kept.view(-1).long().numpy()
+        new_aabb = quiet(ml.updateAlphaMask, (20, 24, 28))
+        rec["upd/alpha"] = ml.alphaMask.alpha_volume[0, 0].numpy().astype(np.uint8)
+        rec["upd/new_aabb"] = new_aabb.numpy()
+        quiet(ml.shrink, new_aabb)
+        for k, v in ml.state_dict().items():
+            if not k.startswith("alphaMask"):
+                rec["shrunk/" + k] = v.numpy().copy()
+        rec["shrunk/aabb"] = ml.aabb.numpy().copy()
+        rec["shrunk/gridSize"] = ml.gridSize.numpy().copy()
+        rec["shrunk/stepSize"] = np.float32(ml.stepSize.item())
+        rec["shrunk/nSamples"] = np.int64(ml.nSamples)
+        quiet(ml.upsample_volume_grid, [36, 40, 30])
+        for k, v in ml.state_dict().items():
+            if k.startswith("density_") or k.startswith("app_"):
+                rec["up/" + k] = v.numpy().copy()
+        rec["up/stepSize"] = np.float32(ml.stepSize.item())
+        rec["up/nSamples"] = np.int64(ml.nSamples)
+        rr = outside_rays(64, 93)
+        rgb, depth, nv = ml(rr, None, white_bg=True, is_train=False)
+        rec["up/rays"] = rr.numpy()
+        rec["up/rgb_map"] = rgb.numpy()
+        rec["up/depth_map"] = depth.numpy()
+        rec["up/num_valid"] = np.int64(nv.item())
+    np.savez_compressed(os.path.join(OUT, "lifecycle.npz"), **rec)
+    print("lifecycle done: alpha kept", int(rec["upd/alpha"].sum()), "bbox kept", len(rec["filter_bbox_kept"]),
+          "alpha-filter kept", len(rec["filter_alpha_kept"]), "shrunk grid", rec["shrunk/gridSize"], "up nSamples", rec["up/nSamples"],
+          "valid", rec["up/num_valid"])
+
     # 9: utils.get_free_mask / N_to_reso / cal_n_samples (pure torch/numpy functions in a module that
     # imports four absent, unrelated packages -> gated with empty stubs for this import only)
     for name in ("cv2", "torchvision", "torchvision.transforms", "plyfile", "skimage", "skimage.measure"):

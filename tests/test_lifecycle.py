@@ -1,0 +1,104 @@
+"""alpha-volume rebuild, ray filtering, shrink, grid up-sampling and the regularisers
+against golden outputs of the reference's own methods (tests/golden/lifecycle.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from tests._golden import _npz
+
+ARGS = dict(step_ratio=0.5, fea2denseAct="softplus", density_n_comp=[8, 8, 8], app_n_comp=[16, 16, 16], app_dim=27,
+            density_shift=-10.0, distance_scale=25.0, alphaMask_thres=0.001, shadingMode="MLP_Fea", pos_pe=2, view_pe=2,
+            fea_pe=2, featureC=64)
+CUBE = [[-1.5, -1.5, -1.5], [1.5, 1.5, 1.5]]
+
+
+def make(recon, z, device, prefix="state0/"):
+    model = recon.TensorVMSplit(ARGS, torch.tensor(CUBE, device=device), [32, 32, 32], [2.0, 6.0], device)
+    model.load_state_dict({k[len(prefix):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix)})
+    model.alphaMask = recon.AlphaGridMask(device, torch.tensor(CUBE, device=device),
+                                          torch.from_numpy(z["alpha0"]).float().to(device))
+    return model
+
+
+def test_shrink_and_upsample_on_cpu(recon):
+    """Host-side schedule steps (torch crop / resize on channel-last parameters) reproduce the reference."""
+    z = _npz("lifecycle")
+    model = make(recon, z, "cpu")
+    model.alphaMask = recon.AlphaGridMask("cpu", torch.tensor(CUBE), torch.from_numpy(z["upd/alpha"]).float())
+    model.shrink(torch.from_numpy(z["upd/new_aabb"]))
+    assert model.gridSize.tolist() == z["shrunk/gridSize"].tolist()
+    assert np.allclose(model.aabb.numpy(), z["shrunk/aabb"], atol=0, rtol=0)
+    assert float(model.stepSize) == float(z["shrunk/stepSize"]) and model.nSamples == int(z["shrunk/nSamples"])
+    for k, p in model.named_parameters():
+        assert np.array_equal(p.detach().numpy(), z["shrunk/" + k]), k
+        if "_plane." in k or "_line." in k:
+            assert recon.is_channel_last(p), k
+    model.upsample_volume_grid([36, 40, 30])
+    assert float(model.stepSize) == float(z["up/stepSize"]) and model.nSamples == int(z["up/nSamples"])
+    for k, p in model.named_parameters():
+        if k.startswith("density_") or k.startswith("app_"):
+            np.testing.assert_allclose(p.detach().numpy(), z["up/" + k], rtol=1e-6, atol=1e-7, err_msg=k)
+            assert recon.is_channel_last(p), k
+    groups = model.get_optparam_groups(0.02, 1e-3)
+    assert sum(p.numel() for g in groups for p in g["params"]) == sum(p.numel() for p in model.parameters())
+
+
+def test_regularisers_match_reference(recon):
+    z = _npz("lifecycle")
+    model = make(recon, z, "cpu")
+    assert abs(float(model.vector_comp_diffs()) - float(z["reg/vector_comp_diffs"])) < 1e-6
+    assert abs(float(model.density_L1()) - float(z["reg/density_L1"])) < 1e-6
+    x = model.density_plane[0]
+    h = ((x[:, :, 1:, :] - x[:, :, :-1, :]) ** 2).sum() / (x.shape[1] * (x.shape[2] - 1) * x.shape[3])
+    w = ((x[:, :, :, 1:] - x[:, :, :, :-1]) ** 2).sum() / (x.shape[1] * x.shape[2] * (x.shape[3] - 1))
+    tv = recon.TVLoss()
+    assert abs(float(tv(x)) - float(2 * (h + w))) < 1e-6                      # loss.py:125-141
+    assert abs(float(model.TV_loss_density(tv)) - sum(float(tv(p)) * 1e-2 for p in model.density_plane)) < 1e-7
+    loss = model.TV_loss_app(tv) + model.density_L1() + model.vector_comp_diffs()
+    loss.backward()
+    assert all(p.grad is not None for p in list(model.app_plane) + list(model.density_line))
+
+
+@pytest.mark.gpu
+def test_alpha_rebuild_filtering_and_schedule_on_gpu(recon):
+    z = _npz("lifecycle")
+    dev = "cuda:0"
+    model = make(recon, z, dev)
+    pts = torch.from_numpy(z["pts"]).to(dev)
+    np.testing.assert_allclose(model.alphaMask.sample_alpha(pts).cpu().numpy(), z["sample_alpha"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(model.compute_alpha(pts, None, model.stepSize).cpu().numpy(), z["compute_alpha"],
+                               rtol=1e-4, atol=1e-6)
+    # filtering_rays: identical survivor sets
+    frays = torch.from_numpy(z["frays"])
+    idx = torch.arange(frays.shape[0]).float()[:, None]
+    _, kept = model.filtering_rays(frays, idx, bbox_only=True)
+    assert kept.view(-1).long().tolist() == z["filter_bbox_kept"].tolist()
+    _, kept = model.filtering_rays(frays, idx, N_samples=64)
+    assert kept.view(-1).long().tolist() == z["filter_alpha_kept"].tolist()
+    # alpha-volume rebuild: same occupancy up to threshold ties, same tight bbox within a voxel
+    new_aabb = model.updateAlphaMask((20, 24, 28))
+    got = model.alphaMask.alpha_volume[0, 0].cpu().numpy() > 0.5
+    ref = z["upd/alpha"] > 0
+    assert got.shape == ref.shape and (got != ref).mean() < 2e-3, (got != ref).sum()
+    voxel = 3.0 / np.array([19, 23, 27])
+    assert np.all(np.abs(new_aabb.cpu().numpy() - z["upd/new_aabb"]) <= voxel + 1e-6)
+    # continue the schedule from the reference's own mask / bbox so later steps compare exactly
+    model.alphaMask = recon.AlphaGridMask(dev, torch.tensor(CUBE, device=dev), torch.from_numpy(z["upd/alpha"]).float().to(dev))
+    model.shrink(torch.from_numpy(z["upd/new_aabb"]).to(dev))
+    assert model.gridSize.tolist() == z["shrunk/gridSize"].tolist()
+    model.upsample_volume_grid([36, 40, 30])
+    assert model.nSamples == int(z["up/nSamples"])
+    rays = torch.from_numpy(z["up/rays"]).to(dev)
+    with torch.no_grad():
+        rgb, depth, nv = model(rays, None, white_bg=True, is_train=False)
+    assert int(nv) == int(z["up/num_valid"])
+    np.testing.assert_allclose(rgb.cpu().numpy(), z["up/rgb_map"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(depth.cpu().numpy(), z["up/depth_map"], rtol=1e-4, atol=1e-5)
+    # and the model still trains after the schedule steps (new parameters, new workspaces)
+    opt = torch.optim.Adam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+    rgb, _, _ = model(rays, None, white_bg=True, is_train=True)
+    loss = torch.mean((rgb - 0.5) ** 2) + 1e-3 * model.TV_loss_density(recon.TVLoss()) + 1e-4 * model.density_L1()
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    assert all(torch.isfinite(p).all() for p in model.parameters())
