@@ -102,3 +102,30 @@ def test_alpha_rebuild_filtering_and_schedule_on_gpu(recon):
     loss.backward()
     opt.step()
     assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+@pytest.mark.gpu
+def test_training_harness_runs_the_intended_schedule(recon):
+    """harness.train: MSE + regularisers, alpha-mask update + shrink, up-sampling with optimizer rebuild (row f-2)."""
+    from recon_amd import synthetic as S, harness
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    aabb = torch.tensor(S.LEGO_AABB, device=dev)
+    args = S.lego_args(density_n_comp=(8, 8, 8), app_n_comp=(16, 16, 16))
+    args["featureC"] = 64
+    teacher = recon.TensorVMSplit(args, aabb, [32] * 3, S.LEGO_NEAR_FAR, dev)
+    S.make_trained_like(teacher, recon.AlphaGridMask, mask_res=32)
+    rays = S.blender_rays(3, H=48, W=48, seed=3).to(dev)
+    with torch.no_grad():
+        gt = recon.OctreeRender_trilinear_fast(rays, teacher, chunk=4096, white_bg=True, device=dev)[0]
+    student = recon.TensorVMSplit(args, aabb, [16] * 3, S.LEGO_NEAR_FAR, dev)
+    cfg = dict(n_iters=60, batch_size=1024, N_voxel_init=16 ** 3, N_voxel_final=32 ** 3, upsamp_list=[30, 45],
+               update_AlphaMask_list=[20], TV_weight_density=0.01, TV_weight_app=0.01, L1_weight_inital=8e-5,
+               L1_weight_rest=4e-5, Ortho_weight=0.01)
+    hist = harness.train(student, rays, gt, cfg, device=dev, log_every=10, seed=1)
+    kinds = [e[1] for e in hist["events"]]
+    assert kinds == ["shrink", "upsample", "upsample"], hist["events"]
+    assert hist["psnr"][-1][1] > hist["psnr"][0][1] + 3.0, hist["psnr"]
+    assert student.alphaMask is not None and all(torch.isfinite(p).all() for p in student.parameters())
+    p = harness.evaluate_psnr(student, rays[:2304], gt[:2304], device=dev)
+    assert p > 15.0, p
