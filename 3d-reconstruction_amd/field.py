@@ -676,6 +676,8 @@ class TensorBase(nn.Module):
         alpha[alpha < self.alphaMask_thres] = 0
         self.alphaMask = AlphaGridMask(self.device, self.aabb, alpha)
         valid_xyz = dense_xyz[alpha > 0.5]
+        if valid_xyz.shape[0] == 0:  # the reference fails here too (amin of an empty tensor)
+            raise IndexError("updateAlphaMask: no voxel reaches alphaMask_thres=%g" % self.alphaMask_thres)
         xyz_min = valid_xyz.amin(0)
         xyz_max = valid_xyz.amax(0)
         new_aabb = torch.stack((xyz_min, xyz_max))

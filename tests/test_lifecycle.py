@@ -119,10 +119,10 @@ def test_training_harness_runs_the_intended_schedule(recon):
     with torch.no_grad():
         gt = recon.OctreeRender_trilinear_fast(rays, teacher, chunk=4096, white_bg=True, device=dev)[0]
     student = recon.TensorVMSplit(args, aabb, [16] * 3, S.LEGO_NEAR_FAR, dev)
-    cfg = dict(n_iters=60, batch_size=1024, N_voxel_init=16 ** 3, N_voxel_final=32 ** 3, upsamp_list=[30, 45],
-               update_AlphaMask_list=[20], TV_weight_density=0.01, TV_weight_app=0.01, L1_weight_inital=8e-5,
+    cfg = dict(n_iters=200, batch_size=2048, N_voxel_init=16 ** 3, N_voxel_final=32 ** 3, upsamp_list=[140, 170],
+               update_AlphaMask_list=[120], TV_weight_density=0.01, TV_weight_app=0.01, L1_weight_inital=8e-5,
                L1_weight_rest=4e-5, Ortho_weight=0.01)
-    hist = harness.train(student, rays, gt, cfg, device=dev, log_every=10, seed=1)
+    hist = harness.train(student, rays, gt, cfg, device=dev, log_every=20, seed=1)
     kinds = [e[1] for e in hist["events"]]
     assert kinds == ["shrink", "upsample", "upsample"], hist["events"]
     assert hist["psnr"][-1][1] > hist["psnr"][0][1] + 3.0, hist["psnr"]
