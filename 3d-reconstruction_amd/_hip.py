@@ -75,6 +75,19 @@ class TfBinJob(C.Structure):
                 ("nkeys", C.c_int)]
 
 
+ADAM_MAX_SEG, ADAM_CHUNK = 32, 8192
+
+
+class TfAdamSeg(C.Structure):
+    _fields_ = [("p", _fp), ("g", _fp), ("m", _fp), ("v", _fp), ("n", C.c_longlong), ("group", C.c_int), ("pad_", C.c_int)]
+
+
+class TfAdamJob(C.Structure):
+    _fields_ = [("n_seg", C.c_int), ("pad_", C.c_int), ("seg", TfAdamSeg * ADAM_MAX_SEG),
+                ("chunk_end", C.c_int * ADAM_MAX_SEG), ("lrs", _fp), ("step", _fp),
+                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double)]
+
+
 class HipError(RuntimeError):
     pass
 
@@ -103,6 +116,7 @@ _SIGS = {
     "tf_binned_scatter": [C.POINTER(TfBinJob), _fp],
     "tf_shade_backward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp,
                           C.POINTER(TfShadeGrads), _fp],
+    "tf_adam_step": [C.POINTER(TfAdamJob), _fp],
 }
 EXPORTS = tuple(_SIGS) + ("tf_build_info",)
 

@@ -1,0 +1,77 @@
+// adam.hip — one-launch Adam step over every parameter of the field.
+// Replaces torch.optim.Adam(...).step() of train.py:272-273 / :376 (betas (0.9, 0.99), eps 1e-8, no weight
+// decay, no amsgrad):   m <- b1 m + (1-b1) g,   v <- b2 v + (1-b2) g^2,
+//                       p <- p - (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps).
+// HBM-bound: 7 streams (p, m, v read+write, g read) of sum(numel) floats.  The parameter tensors, their
+// gradients (views of the backward's contiguous gradient buffer) and the moment buffers are walked in STORAGE
+// order (channel-last planes are dense in storage), 16 B per lane.  The segment table travels in the kernel
+// arguments, so a hipGraph capture bakes the pointers in and nothing is read from host-updated tables; the
+// learning rates and the step count are read from device memory (they change per step under graph replay).
+#include "tf_device.h"
+
+namespace {
+
+constexpr int kChunk = TF_ADAM_CHUNK;   // elements per workgroup
+
+__global__ __launch_bounds__(256) void adam_kernel(const TfAdamJob J) {
+    __shared__ float s_hyp[2];
+    __shared__ int s_seg;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int s = 0;
+        while (s + 1 < J.n_seg && (int)blockIdx.x >= J.chunk_end[s]) ++s;
+        s_seg = s;
+        const double t = (double)*J.step;
+        const double bc1 = 1.0 - pow(J.beta1, t), bc2 = 1.0 - pow(J.beta2, t);
+        s_hyp[0] = (float)((double)J.lrs[J.seg[s].group] / (double)(float)bc1);   // step size
+        s_hyp[1] = (float)sqrt(bc2);
+    }
+    __syncthreads();
+    const TfAdamSeg& sg = J.seg[s_seg];
+    const float step_size = s_hyp[0], bc2_sqrt = s_hyp[1];
+    const long long c0 = (long long)((int)blockIdx.x - (s_seg ? J.chunk_end[s_seg - 1] : 0)) * kChunk;
+    const long long n = sg.n - c0 < kChunk ? sg.n - c0 : kChunk;
+    float* __restrict__ p = sg.p + c0;
+    const float* __restrict__ g = sg.g + c0;
+    float* __restrict__ m = sg.m + c0;
+    float* __restrict__ v = sg.v + c0;
+    const double b1 = J.beta1, b2 = J.beta2, eps = J.eps;
+    auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+        mm = (float)(b1 * (double)mm + (1.0 - b1) * (double)gg);
+        vv = (float)(b2 * (double)vv + (1.0 - b2) * (double)gg * (double)gg);
+        const float denom = (float)((double)(sqrtf(vv) / bc2_sqrt) + eps);
+        pp -= step_size * mm / denom;
+    };
+    const long long n4 = n >> 2;
+#pragma unroll 2
+    for (long long i = tid; i < n4; i += 256) {
+        tf::float4_t pv = tf::ld4(p + 4 * i), mv = tf::ld4(m + 4 * i), vv = tf::ld4(v + 4 * i);
+        const tf::float4_t gv = tf::ld4(g + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float pe = pv[e], me = mv[e], ve = vv[e];
+            upd(pe, gv[e], me, ve);
+            pv[e] = pe; mv[e] = me; vv[e] = ve;
+        }
+        *reinterpret_cast<tf::float4_t*>(p + 4 * i) = pv;
+        *reinterpret_cast<tf::float4_t*>(m + 4 * i) = mv;
+        *reinterpret_cast<tf::float4_t*>(v + 4 * i) = vv;
+    }
+    for (long long i = 4 * n4 + tid; i < n; i += 256) upd(p[i], g[i], m[i], v[i]);
+}
+
+}  // namespace
+
+extern "C" int tf_adam_step(const TfAdamJob* job, tf_stream_t stream) {
+    if (job->n_seg < 1 || job->n_seg > TF_ADAM_MAX_SEG || !job->lrs || !job->step) return (int)hipErrorInvalidValue;
+    for (int s = 0; s < job->n_seg; ++s) {
+        const TfAdamSeg& sg = job->seg[s];
+        // 16-B lanes: every stream of a segment must be 16-B aligned
+        if (((uintptr_t)sg.p | (uintptr_t)sg.g | (uintptr_t)sg.m | (uintptr_t)sg.v) & 15) return (int)hipErrorInvalidValue;
+        const long long chunks = (sg.n + kChunk - 1) / kChunk;
+        const int prev = s ? job->chunk_end[s - 1] : 0;
+        if (sg.n <= 0 || job->chunk_end[s] - prev != chunks) return (int)hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)job->chunk_end[job->n_seg - 1]), dim3(256), 0, (hipStream_t)stream, *job);
+    return TF_CHECK_LAUNCH();
+}

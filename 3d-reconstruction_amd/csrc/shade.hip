@@ -24,9 +24,8 @@ __global__ __launch_bounds__(256) void shade_forward_kernel(const TfShade S, con
     int* pre = reinterpret_cast<int*>(lds + L.offPre);
     float* regA = lds + L.offA;   // V, then H1
     float* regB = lds + L.offB;   // X, then H2
-    int* iray = reinterpret_cast<int*>(lds + L.offInfo);
-    float* ixyz = lds + L.offInfo + M;       // [64][3]
-    float* iview = lds + L.offInfo + 4 * M;  // [64][3]
+    float* ixyz = lds + L.offInfo;           // [64][3]
+    float* iview = lds + L.offInfo + 3 * M;  // [64][3]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
     if (src.counters) {   // tile prefix over shards (every workgroup computes the same table)
@@ -58,13 +57,12 @@ __global__ __launch_bounds__(256) void shade_forward_kernel(const TfShade S, con
 
         // ---- tile info
         if (tid < M) {
-            int ray = 0;
             float x[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f};
             if (tid < n) {
                 const size_t s = (size_t)s0 + tid;
                 x[0] = src.app_xyz[s * 3]; x[1] = src.app_xyz[s * 3 + 1]; x[2] = src.app_xyz[s * 3 + 2];
                 if (src.rays) {
-                    ray = src.app_ray[s];
+                    const int ray = src.app_ray[s];
                     const float* rp = src.rays + (size_t)ray * 6 + 3;
                     v[0] = rp[0]; v[1] = rp[1]; v[2] = rp[2];
                     if (src.ndc) {   // viewdirs / rays_norm  (tensorBase.py:341-343)
@@ -76,7 +74,6 @@ __global__ __launch_bounds__(256) void shade_forward_kernel(const TfShade S, con
                     }
                 }
             }
-            iray[tid] = ray;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 ixyz[tid * 3 + a] = x[a];

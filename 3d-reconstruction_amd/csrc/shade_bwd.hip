@@ -101,7 +101,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                                                                  const float* __restrict__ grad_rgb,
                                                                  const TfShadeGrads G) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NT = 512, NW = 8, SG = NW / FT, NSW = 4 / SG, NW2 = FT / SG, KT1S = KT1 / SG, KTBW = 3;
+    constexpr int NT = 512, NW = 8, SG = NW / FT, NSW = 4 / SG, NW2 = FT / SG, KT1S = KT1 / SG;
     const BwdLds L = bwd_lds(S);
     float* V = lds + L.offV;
     float* X = lds + L.offX;
@@ -114,10 +114,8 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
     float* ixyz = lds + L.offInfo + M;
     float* iview = lds + L.offInfo + 4 * M;
     int* pre = reinterpret_cast<int*>(lds + L.offPre);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x;
     const int FC = S.feature_c, kp1 = kpad16(S.in_c), kt1 = kp1 / 16, kpB = kpad16(S.n_app_total), ktB = kpB / 16;
-    const int my_ft = wave % FT, my_sg = wave / FT, s_base = my_sg * NSW * 16;
-    const int lc = lane & 15, lg = lane >> 4;
 
     // ---- weight-gradient slab of this workgroup (fragment order: [tile][lane][4]) and the few scalars that
     // do live in registers across tiles
@@ -139,47 +137,73 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         __syncthreads();
     }
 
+    // per-sample tile info of thread tid < 64, loaded for the NEXT tile while the current one is processed
+    int nx_ray = 0;
+    float nx_x[3] = {0.f, 0.f, 0.f}, nx_v[3] = {0.f, 0.f, 0.f};
+    auto fetch_info = [&](int s0_, int n_) {
+        nx_ray = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) nx_x[a] = nx_v[a] = 0.f;
+        if (tid < n_) {
+            const size_t s = (size_t)s0_ + tid;
+            nx_x[0] = src.app_xyz[s * 3]; nx_x[1] = src.app_xyz[s * 3 + 1]; nx_x[2] = src.app_xyz[s * 3 + 2];
+            nx_ray = src.app_ray[s];
+            const float* rp = src.rays + (size_t)nx_ray * 6 + 3;
+            nx_v[0] = rp[0]; nx_v[1] = rp[1]; nx_v[2] = rp[2];
+        }
+    };
+    {
+        int s1, n1;
+        if (tid < M && locate_tile(src, pre, (int)blockIdx.x, s1, n1)) fetch_info(s1, n1);
+    }
+    const bool quads = vm_quads_ok(S);
+
     TF_T0();
     for (int t = blockIdx.x;; t += gridDim.x) {
         int s0, n;
         if (!locate_tile(src, pre, t, s0, n)) break;
+        // Thread coordinates are re-derived per tile from an opaque copy of the thread id: otherwise the compiler
+        // hoists every phase's per-thread addresses out of the tile loop and runs out of registers (scratch
+        // spills, which also break hipGraph replay on this stack).
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int wave = tid >> 6, lane = tid & 63;
+        const int my_ft = wave % FT, my_sg = wave / FT, s_base = my_sg * NSW * 16;
+        const int lc = lane & 15, lg = lane >> 4;
 
-        // ---- tile info
+        // ---- tile info (fetched one tile ahead: app_ray -> rays is a chain of two global latencies)
         if (tid < M) {
-            int ray = 0;
-            float x[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f};
-            if (tid < n) {
-                const size_t s = (size_t)s0 + tid;
-                x[0] = src.app_xyz[s * 3]; x[1] = src.app_xyz[s * 3 + 1]; x[2] = src.app_xyz[s * 3 + 2];
-                ray = src.app_ray[s];
-                const float* rp = src.rays + (size_t)ray * 6 + 3;
-                v[0] = rp[0]; v[1] = rp[1]; v[2] = rp[2];
-                if (src.ndc) {
-                    float q = v[0] * v[0];
-                    q = q + v[1] * v[1];
-                    q = q + v[2] * v[2];
-                    const float nrm = sqrtf(q);
-                    v[0] = v[0] / nrm; v[1] = v[1] / nrm; v[2] = v[2] / nrm;
-                }
+            if (src.ndc && tid < n) {   // viewdirs / rays_norm  (tensorBase.py:341-343)
+                float q = nx_v[0] * nx_v[0];
+                q = q + nx_v[1] * nx_v[1];
+                q = q + nx_v[2] * nx_v[2];
+                const float nrm = sqrtf(q);
+                nx_v[0] = nx_v[0] / nrm; nx_v[1] = nx_v[1] / nrm; nx_v[2] = nx_v[2] / nrm;
             }
-            iray[tid] = ray;
+            iray[tid] = nx_ray;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                ixyz[tid * 3 + a] = x[a];
-                iview[tid * 3 + a] = v[a];
+                ixyz[tid * 3 + a] = nx_x[a];
+                iview[tid * 3 + a] = nx_v[a];
             }
         }
-        __syncthreads();
+        lds_barrier();
+        {
+            int s1, n1;
+            if (tid < M && locate_tile(src, pre, t + (int)gridDim.x, s1, n1)) fetch_info(s1, n1);
+        }
 
         // ================= forward recompute =================
         {   // gather -> V, 8 lanes per sample
             const int smp = wave * 8 + (lane >> 3), sub = lane & 7;
             float u[3] = {ixyz[smp * 3], ixyz[smp * 3 + 1], ixyz[smp * 3 + 2]};
             float* vrow = V + smp * L.sv;
-            app_products(S, u, sub, vrow, 8);
+            if (quads) app_products_vm_batched<5>(S, u, sub, 8, vrow);
+            else app_products(S, u, sub, vrow, 8);
             for (int c = S.n_app_total + sub; c < kpB; c += 8) vrow[c] = 0.f;
         }
-        __syncthreads();
+        lds_barrier();
+        TF_MARK(8);
         if (wave < 4 * NB) {   // basis -> X[:, :app_dim]: one (feature tile, sample tile) per wave
             const int bf = wave >> 2, bs = wave & 3;
             f32x4 acc[1][1];
@@ -196,7 +220,8 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
 #pragma unroll
             for (int a = 0; a < 3; ++a) X[tid * L.sx + S.app_dim + a] = iview[tid * 3 + a];
         }
-        __syncthreads();
+        lds_barrier();
+        TF_MARK(9);
         {   // PE blocks + zero padding
             int off = S.app_dim + 3;
             for (int b = 0; b < S.n_pe; ++b) {
@@ -231,7 +256,8 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                 X[smp * L.sx + c] = 0.f;
             }
         }
-        __syncthreads();
+        lds_barrier();
+        TF_MARK(10);
         {   // layer 1 -> H1
             f32x4 acc[1][NSW];
             zero_acc(acc);
@@ -246,7 +272,8 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                 *reinterpret_cast<f32x4*>(H1 + (s_base + 16 * j + lc) * L.sh + f) = h;
             }
         }
-        __syncthreads();
+        lds_barrier();
+        TF_MARK(11);
         {   // layer 2 -> H2
             f32x4 acc[1][NSW];
             zero_acc(acc);
@@ -261,7 +288,8 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                 *reinterpret_cast<f32x4*>(H2 + (s_base + 16 * j + lc) * L.sh + f) = h;
             }
         }
-        __syncthreads();
+        lds_barrier();
+        TF_MARK(12);
         {   // output layer, sigmoid, do = dL/dc * c (1 - c); 8 lanes per sample
             const int smp = tid >> 3, sub = tid & 7;
             const float* h = H2 + smp * L.sh;
@@ -290,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                 dO[smp * 4 + sub] = d;
             }
         }
-        __syncthreads();
+        lds_barrier();
         TF_MARK(0);
 
         // ================= backward =================
@@ -313,21 +341,23 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                 ab3 += a;
             }
         }
-        __syncthreads();
+        lds_barrier();
         TF_MARK(1);
         {   // dW2[f2][f1] += sum_s dZ2[s][f2] H1[s][f1]
-            f32x4 aW2[1][NW2];
+            // the slab's running sum is fetched now and added after the MFMA loop: its latency hides behind the loop
+            f32x4 aW2[1][NW2], run[NW2];
 #pragma unroll
             for (int j = 0; j < NW2; ++j) {
                 float* sp = slabW2 + ((size_t)(my_ft * FT + NW2 * my_sg + j) * 64 + lane) * 4;
-                aW2[0][j] = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(sp);
+                run[j] = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(sp);
             }
+            zero_acc(aW2);
             mma_gen<1, NW2, COL, COL>(H2, L.sh, 16 * my_ft, H1, L.sh, 16 * NW2 * my_sg, M / 16, aW2);
 #pragma unroll
             for (int j = 0; j < NW2; ++j)
-                *reinterpret_cast<f32x4*>(slabW2 + ((size_t)(my_ft * FT + NW2 * my_sg + j) * 64 + lane) * 4) = aW2[0][j];
+                *reinterpret_cast<f32x4*>(slabW2 + ((size_t)(my_ft * FT + NW2 * my_sg + j) * 64 + lane) * 4) = aW2[0][j] + run[j];
         }
-        __syncthreads();   // every wave is done reading H1 for dW2
+        lds_barrier();   // every wave is done reading H1 for dW2
         TF_MARK(2);
         {   // dH1[f1][s] = sum_f2 W2[f2][f1] dZ2[s][f2];  dZ1 = dH1 . [H1 > 0] written in place of H1
             f32x4 acc[1][NSW];
@@ -344,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                 *reinterpret_cast<f32x4*>(hp) = dz;
             }
         }
-        __syncthreads();
+        lds_barrier();
         TF_MARK(3);
         {   // db1 += column sums of dZ1
             float a = 0.f;
@@ -356,12 +386,13 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {      // two passes over the k tiles: half the accumulator registers
             constexpr int KH = KT1S / 2;
-            f32x4 aW1[KH];
+            f32x4 aW1[KH], run[KH];
 #pragma unroll
             for (int q = 0; q < KH; ++q) {
                 const int j = my_sg + SG * (half * KH + q);
-                aW1[q] = (first || j >= kt1) ? (f32x4){0.f, 0.f, 0.f, 0.f}
+                run[q] = (first || j >= kt1) ? (f32x4){0.f, 0.f, 0.f, 0.f}
                                              : *reinterpret_cast<const f32x4*>(slabW1 + ((size_t)(my_ft * kt1 + j) * 64 + lane) * 4);
+                aW1[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll 1
             for (int kg = 0; kg < M / 16; ++kg) {
@@ -381,14 +412,14 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
 #pragma unroll
             for (int q = 0; q < KH; ++q) {
                 const int j = my_sg + SG * (half * KH + q);
-                if (j < kt1) *reinterpret_cast<f32x4*>(slabW1 + ((size_t)(my_ft * kt1 + j) * 64 + lane) * 4) = aW1[q];
+                if (j < kt1) *reinterpret_cast<f32x4*>(slabW1 + ((size_t)(my_ft * kt1 + j) * 64 + lane) * 4) = aW1[q] + run[q];
             }
         }
-        __syncthreads();   // dW1 finished reading X; the H2 region (dZ2) is free
+        lds_barrier();   // dW1 finished reading X; the H2 region (dZ2) is free
         TF_MARK(4);
         for (int smp = wave; smp < M; smp += NW)             // feat copy for the PE derivative
             if (lane < S.app_dim) Fs[smp * L.sf + lane] = X[smp * L.sx + lane];
-        __syncthreads();
+        lds_barrier();
         // dX[k][s] = sum_f W1[f][k] dZ1[s][f], written in place of X; wave w owns k tiles w, w+8, ...
         for (int kt = wave; kt < kt1; kt += NW) {
             f32x4 acc[1][4];
@@ -398,7 +429,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
             for (int j = 0; j < 4; ++j)
                 *reinterpret_cast<f32x4*>(X + (16 * j + lc) * L.sx + 16 * kt + 4 * lg) = acc[0][j];
         }
-        __syncthreads();
+        lds_barrier();
         TF_MARK(5);
         {   // dfeat = dX[:, :D] + PE'(feat): d/dx [sin(x 2^k) m_s] = cos(.) 2^k m_s,  d/dx [cos(.) m_c] = -sin(.) 2^k m_c
             for (int it = tid; it < M * 16 * NB; it += NT) {
@@ -431,20 +462,21 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                 Fd[smp * L.sf + d] = gsum;
             }
         }
-        __syncthreads();
+        lds_barrier();
         // dB[f][c] += sum_s dfeat[s][f] V[s][c]; wave w owns column tiles w, w+8, ...
         for (int ct = wave; ct < ktB; ct += NW) {
-            f32x4 one[NB][1];
+            f32x4 one[NB][1], run[NB];
 #pragma unroll
             for (int i = 0; i < NB; ++i)
-                one[i][0] = first ? (f32x4){0.f, 0.f, 0.f, 0.f}
-                                  : *reinterpret_cast<const f32x4*>(slabB + ((size_t)(i * ktB + ct) * 64 + lane) * 4);
+                run[i] = first ? (f32x4){0.f, 0.f, 0.f, 0.f}
+                               : *reinterpret_cast<const f32x4*>(slabB + ((size_t)(i * ktB + ct) * 64 + lane) * 4);
+            zero_acc(one);
             mma_gen<NB, 1, COL, COL>(Fd, L.sf, 0, V, L.sv, 16 * ct, M / 16, one);
 #pragma unroll
             for (int i = 0; i < NB; ++i)
-                *reinterpret_cast<f32x4*>(slabB + ((size_t)(i * ktB + ct) * 64 + lane) * 4) = one[i][0];
+                *reinterpret_cast<f32x4*>(slabB + ((size_t)(i * ktB + ct) * 64 + lane) * 4) = one[i][0] + run[i];
         }
-        __syncthreads();   // dB finished reading V
+        lds_barrier();   // dB finished reading V
         // dV[c][s] = sum_f B[f][c] dfeat[s][f], written in place of V
         for (int ct = wave; ct < ktB; ct += NW) {
             f32x4 acc[1][4];
@@ -454,14 +486,14 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
             for (int j = 0; j < 4; ++j)
                 *reinterpret_cast<f32x4*>(V + (16 * j + lc) * L.sv + 16 * ct + 4 * lg) = acc[0][j];
         }
-        __syncthreads();
+        lds_barrier();
         TF_MARK(6);
         // hand dL/dV to the scatter stage (tf_binned_scatter for VM, app_direct_scatter_kernel otherwise)
         for (int smp = wave; smp < n; smp += NW)
             for (int c = lane; c < S.n_app_total; c += 64)
                 G.dv_out[((size_t)s0 + smp) * S.n_app_total + c] = V[smp * L.sv + c];
         first = false;
-        __syncthreads();
+        lds_barrier();
         TF_MARK(7);
     }
     TF_FLUSH();
@@ -494,7 +526,7 @@ __global__ __launch_bounds__(256) void wslab_reduce_kernel(const TfShade S, cons
     }
     __syncthreads();
     const int active = s_active;
-    const int FT = S.feature_c / 16, kt1 = kpad16(S.in_c) / 16, NB = (S.app_dim + 15) / 16, ktB = kpad16(S.n_app_total) / 16;
+    const int FT = S.feature_c / 16, kt1 = kpad16(S.in_c) / 16, ktB = kpad16(S.n_app_total) / 16;
     const size_t stride = wslab_floats(S);
     const int tile = blockIdx.x;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
@@ -590,6 +622,10 @@ bwd_fn_t pick_bwd(const TfShade& S) {
 
 }  // namespace
 
+#ifdef TF_PHASE_TIMING
+static int g_dbg_bwd_wgs = 256;
+#endif
+
 extern "C" {
 
 int tf_shade_backward(const TfShade* shade, const float* rays, int ndc, const int* counters, int seg_cap,
@@ -604,7 +640,11 @@ int tf_shade_backward(const TfShade* shade, const float* rays, int ndc, const in
     if (e != hipSuccess) return (int)e;
     if (!grads->dv_out || !grads->wslab || !shade->w1t || !shade->w2t) return (int)hipErrorInvalidValue;
     TileSrc src{counters, seg_cap, 0, app_ray, app_xyz, rays, ndc};
+#ifdef TF_PHASE_TIMING
+    const int n_wg = g_dbg_bwd_wgs;
+#else
     const int n_wg = 256;
+#endif
     hipLaunchKernelGGL(fn, dim3(n_wg), dim3(512), bytes, (hipStream_t)stream, *shade, src, grad_rgb, *grads);
     hipLaunchKernelGGL(wslab_reduce_kernel, dim3((unsigned)(wslab_floats(*shade) / 256)), dim3(256), 0, (hipStream_t)stream, *shade,
                        counters, n_wg, *grads);
@@ -614,6 +654,7 @@ int tf_shade_backward(const TfShade* shade, const float* rays, int ndc, const in
 }
 
 #ifdef TF_PHASE_TIMING
+int tf_debug_set_bwd_wgs(int n) { g_dbg_bwd_wgs = n < 1 ? 1 : (n > 256 ? 256 : n); return 0; }
 int tf_debug_set_flags_shade(int flags) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(tf_dbg_flags), &flags, sizeof(int));
 }

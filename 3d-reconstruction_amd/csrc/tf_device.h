@@ -28,9 +28,9 @@ static __device__ int tf_dbg_flags;
 // Diagnostic build only (-DTF_PHASE_TIMING, lib/libtensorf_hip_diag.so): per-phase shader-clock totals.
 #ifdef TF_PHASE_TIMING
 static __device__ unsigned long long tf_phase_cycles[16];
-#define TF_T0() unsigned long long _t = __builtin_readcyclecounter(); unsigned long long _ph[8] = {0,0,0,0,0,0,0,0}
+#define TF_T0() unsigned long long _t = __builtin_readcyclecounter(); unsigned long long _ph[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}
 #define TF_MARK(i) do { unsigned long long _n = __builtin_readcyclecounter(); _ph[i] += _n - _t; _t = _n; } while (0)
-#define TF_FLUSH() do { if (threadIdx.x == 0) for (int _i = 0; _i < 8; ++_i) atomicAdd(&tf_phase_cycles[_i], _ph[_i]); } while (0)
+#define TF_FLUSH() do { if (threadIdx.x == 0) for (int _i = 0; _i < 16; ++_i) atomicAdd(&tf_phase_cycles[_i], _ph[_i]); } while (0)
 #else
 #define TF_T0()
 #define TF_MARK(i)
@@ -38,6 +38,11 @@ static __device__ unsigned long long tf_phase_cycles[16];
 #endif
 
 typedef float float4_t __attribute__((ext_vector_type(4)));
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains this wave's outstanding GLOBAL
+// loads and stores (s_waitcnt vmcnt(0)), which stalls kernels that keep global stores (or prefetches of the next
+// operands) in flight across phase boundaries.  Use only where the data exchanged between waves lives in LDS.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

@@ -8,15 +8,25 @@ device (sample counts, packed lists, bins), so the captured launch sequence is s
 step is: draw the stratified jitter from the CPU generator exactly like the reference (tensorBase.py:201),
 stage the batch into the static input buffers, replay.
 
+Data parallel (`world_size > 1`): the step is captured as TWO graphs — forward/loss/backward and the optimizer
+step — with the one gradient all-reduce (`parallel.allreduce_gradients`, RCCL) issued eagerly between the two
+replays on the same stream, so no collective is ever inside a capture.
+
 Restrictions (else use the eager path): fixed batch size / N_samples, `white_bg=True` (the random background
-draw of tensorBase.py:380 is a host decision per step), single process (the gradient all-reduce is not
-captured)."""
+draw of tensorBase.py:380 is a host decision per step)."""
 import torch
+import torch.distributed as dist
+
+from . import parallel
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, batch, n_samples, mask=None, ndc_ray=False, warmup=3):
+    def __init__(self, model, optimizer, batch, n_samples, mask=None, ndc_ray=False, warmup=3, split=None):
         self.model, self.opt = model, optimizer
+        # split: capture backward and optimizer separately with the gradient all-reduce in between
+        self.split = (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) if split is None \
+            else bool(split)
+        self.graph_opt = None
         dev = next(model.parameters()).device
         self.rays = torch.zeros(batch, 6, device=dev)
         self.target = torch.zeros(batch, 3, device=dev)
@@ -29,14 +39,19 @@ class GraphedTrainStep:
         # stream, so the autograd AccumulateGrad nodes are bound to the stream that is later captured
         self._side = torch.cuda.Stream(device=dev)
 
-    def _body(self):
+    def _fwd_bwd(self):
         rgb, _, _ = self.model(self.rays, self.mask, white_bg=True, is_train=True, ndc_ray=self.ndc,
                                N_samples=self.n_samples)
         loss = torch.mean((rgb - self.target) ** 2)
         self.opt.zero_grad(set_to_none=True)
         loss.backward()
-        self.opt.step()
         self.loss.copy_(loss.detach())
+
+    def _body(self):
+        self._fwd_bwd()
+        if self.split:
+            parallel.allreduce_gradients(self.model)
+        self.opt.step()
 
     def _stage(self, rays, target):
         self.rays.copy_(rays, non_blocking=True)
@@ -47,8 +62,13 @@ class GraphedTrainStep:
     def step(self, rays, target):
         """One optimisation step on (rays, target); returns the (device) loss tensor of that step."""
         self._stage(rays, target)
+        if hasattr(self.opt, "sync_lr") and self.opt._lr_dev is not None:
+            self.opt.sync_lr()                                    # FusedAdam: lr schedule follows the host values
         if self.graph is not None:
             self.graph.replay()
+            if self.split:
+                parallel.allreduce_gradients(self.model)      # on model.grad_flat: a static buffer of the graph's pool
+                self.graph_opt.replay()
             return self.loss
         self.model.static_jitter = self.jitter
         cur = torch.cuda.current_stream()
@@ -61,8 +81,19 @@ class GraphedTrainStep:
             return self.loss
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
+        if not self.split:
+            with torch.cuda.graph(g, stream=self._side):
+                self._body()
+            self.graph = g
+            g.replay()                                            # capture only records; run this step now
+            return self.loss
         with torch.cuda.graph(g, stream=self._side):
-            self._body()
-        self.graph = g
-        g.replay()                                                # capture only records; run this step now
+            self._fwd_bwd()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, stream=self._side, pool=g.pool()):
+            self.opt.step()
+        self.graph, self.graph_opt = g, g2
+        g.replay()
+        parallel.allreduce_gradients(self.model)
+        g2.replay()
         return self.loss

@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from . import parallel
+from .optim import FusedAdam
 from .regularizers import TVLoss
 from .renderer import OctreeRender_trilinear_fast
 from .utils import N_to_reso, cal_n_samples, get_free_mask
@@ -61,7 +62,13 @@ def train(tensorf, allrays, allrgbs, cfg=None, device="cuda", rank=0, world=1, l
                                                         len(upsamp_list) + 1))).long()).tolist()[1:]   # train.py:209-215
     nSamples = min(int(1e6), cal_n_samples(tensorf.gridSize.tolist(), c["step_ratio"]))
     lr_factor = c["lr_decay_target_ratio"] ** (1 / (c["lr_decay_iters"] if c["lr_decay_iters"] > 0 else n_iters))
-    opt = torch.optim.Adam(tensorf.get_optparam_groups(c["lr_init"], c["lr_basis"]), betas=(0.9, 0.99))
+    def make_opt(lr_xyz, lr_net):     # train.py:272-273; "torch" selects torch.optim.Adam instead of tf_adam_step
+        groups = tensorf.get_optparam_groups(lr_xyz, lr_net)
+        if c.get("optimizer", "fused") == "torch":
+            return torch.optim.Adam(groups, betas=(0.9, 0.99))
+        return FusedAdam(groups, betas=(0.9, 0.99))
+
+    opt = make_opt(c["lr_init"], c["lr_basis"])
     tvreg = TVLoss()
     ortho_w, l1_w = c["Ortho_weight"], c["L1_weight_inital"]
     tv_d, tv_a = c["TV_weight_density"], c["TV_weight_app"]
@@ -113,15 +120,14 @@ def train(tensorf, allrays, allrgbs, cfg=None, device="cuda", rank=0, world=1, l
             if not c["ndc_ray"] and it == mask_list[-1] and len(mask_list) > 1:
                 allrays, allrgbs = tensorf.filtering_rays(allrays, allrgbs)
                 sampler = SimpleSampler(allrays.shape[0], batch * world, seed + it)
-            opt = torch.optim.Adam(tensorf.get_optparam_groups(c["lr_init"] * lr_factor ** it, c["lr_basis"] * lr_factor ** it),
-                                   betas=(0.9, 0.99))
+            opt = make_opt(c["lr_init"] * lr_factor ** it, c["lr_basis"] * lr_factor ** it)
         if it in upsamp_list:                                                              # train.py:468-481
             n_voxels = n_voxel_list.pop(0)
             reso_cur = N_to_reso(n_voxels, tensorf.aabb)
             nSamples = min(int(1e6), cal_n_samples(reso_cur, c["step_ratio"]))
             tensorf.upsample_volume_grid(reso_cur)
             scale = 1.0 if c["lr_upsample_reset"] else c["lr_decay_target_ratio"] ** (it / n_iters)
-            opt = torch.optim.Adam(tensorf.get_optparam_groups(c["lr_init"] * scale, c["lr_basis"] * scale), betas=(0.9, 0.99))
+            opt = make_opt(c["lr_init"] * scale, c["lr_basis"] * scale)
             hist["events"].append((it, "upsample", reso_cur, nSamples))
         hist["n_samples"].append(nSamples)
     return hist

@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--views", type=int, default=3)
     ap.add_argument("--no-baselines", action="store_true", help="skip the CPU / ROCm-eager baseline legs")
     ap.add_argument("--no-graph", action="store_true", help="drive the train step eagerly instead of replaying a hipGraph")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the one-launch tf_adam_step")
     return ap.parse_args()
 
 
@@ -158,11 +159,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # TF_DIST_BACKEND=gloo rehearses the N>1 code path with several ranks sharing one GPU (RCCL refuses that);
+    # the driver's runs use the default, "nccl" (= RCCL), one rank per GPU
+    backend = os.environ.get("TF_DIST_BACKEND", "nccl")
+    local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -178,10 +186,17 @@ def main():
         perm = perm.repeat((need + perm.numel() - 1) // perm.numel())
     perm = perm[:need].view(n_steps, B * world).to(dev)
 
-    # train.py:272-273 (same optimizer, same groups / learning rates); fused=True only changes how torch
-    # batches the elementwise update
-    use_graph = args.mode == "train" and world == 1 and not args.no_graph
-    opt = torch.optim.Adam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), fused=True, capturable=use_graph)
+    # train.py:272-273 (same optimizer, same groups / learning rates, same update rule): FusedAdam applies it in
+    # one launch (tf_adam_step); --torch-adam uses torch's multi-tensor implementation instead
+    use_graph = args.mode == "train" and not args.no_graph
+
+    def make_opt(capturable):
+        groups = model.get_optparam_groups(0.02, 1e-3)
+        if args.torch_adam:
+            return torch.optim.Adam(groups, betas=(0.9, 0.99), fused=True, capturable=capturable)
+        return recon_amd.FusedAdam(groups, betas=(0.9, 0.99))
+
+    opt = make_opt(use_graph)
     graphed = recon_amd.GraphedTrainStep(model, opt, B, n_samples) if use_graph else None
     model.lazy_sample_count = True   # the renderer's 6th return value syncs only when read (train.py never reads it)
     renderer = recon_amd.OctreeRender_trilinear_fast
@@ -205,7 +220,7 @@ def main():
                      is_train=False)
 
     def graph_step(i):
-        ids = perm[i]
+        ids = parallel.shard_ids(perm[i], rank, world)
         return graphed.step(rays[ids], targets[ids])
 
     step = (graph_step if use_graph else train_step) if args.mode == "train" else eval_step
@@ -239,8 +254,7 @@ def main():
     if use_graph:
         # the graph replays cannot carry HIP events, so the per-kernel durations come from an eager pass of the
         # SAME step (same kernels, same batch shapes) run right here, bracketed launch by launch with events
-        opt_e = torch.optim.Adam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), fused=True)
-        opt, model.static_jitter = opt_e, None
+        opt, model.static_jitter = make_opt(False), None
         n_e = min(20, args.steps)
         for i in range(3):
             train_step(i)
@@ -290,7 +304,9 @@ def main():
                        "per_ray": {"in_bbox": stats["bbox"] / B, "density": stats["density"] / B,
                                    "shaded": stats["shaded"] / B},
                        "parallelism": f"ray-sharded dp{world}", "lazy_sample_count": True,
-                       "launch": "hipGraph replay" if use_graph else "eager",
+                       "launch": ("hipGraph replay" if world == 1 else "2 hipGraph replays around one RCCL all-reduce")
+                                 if use_graph else "eager",
+                       "optimizer": "torch.optim.Adam(fused)" if args.torch_adam else "Adam, one launch (tf_adam_step)",
                        "eager_ms_per_step": eager_ms},
             "roofline": roof,
             "kernels": {n: {"avg_ms": round(v["avg_ms"], 5), "GBps": round(v["GBps"], 1),

@@ -248,6 +248,35 @@ int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream);
 /* dst[j] = sum_r rep[r*stride + j], j < numel: folds the line-gradient replicas. */
 int tf_reduce_replicas(const float* rep, int n_rep, int stride, int numel, float* dst, tf_stream_t stream);
 
+/* ---- optimizer step ---------------------------------------------------------------
+ * Replaces `optimizer.step()` of train.py:376 for `torch.optim.Adam(grad_vars, betas=(0.9, 0.99))`
+ * (train.py:272-273; eps 1e-8, no weight decay, no amsgrad).  A segment is one parameter tensor walked in
+ * storage order: p, g (its gradient, same layout), m / v (first / second moment), n elements, `group` selects
+ * the learning rate lrs[group] (train.py uses two: lr_init for the factor tensors, lr_basis for the networks).
+ * chunk_end[s] = number of TF_ADAM_CHUNK-element chunks in segments 0..s (one workgroup per chunk).
+ * `lrs` and `step` are DEVICE pointers (float): step holds the 1-based step count t of this update. */
+#define TF_ADAM_MAX_SEG 32
+#define TF_ADAM_CHUNK 8192
+typedef struct TfAdamSeg {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    long long n;
+    int group;
+    int pad_;
+} TfAdamSeg;
+typedef struct TfAdamJob {
+    int n_seg;
+    int pad_;
+    TfAdamSeg seg[TF_ADAM_MAX_SEG];
+    int chunk_end[TF_ADAM_MAX_SEG];
+    const float* lrs;
+    const float* step;
+    double beta1, beta2, eps;
+} TfAdamJob;
+int tf_adam_step(const TfAdamJob* job, tf_stream_t stream);
+
 /* Library identification: returns the gfx target string the kernels were compiled for. */
 const char* tf_build_info(void);
 

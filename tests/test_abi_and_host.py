@@ -33,7 +33,8 @@ def test_library_exports_every_declared_symbol(recon):
 def test_ctypes_structs_match_header_field_order(recon):
     """Field names of the ctypes mirrors appear in the header's struct bodies in the same order."""
     text = open(os.path.join(ROOT, "include", "tensorf_hip.h")).read()
-    for cname in ("TfFactors", "TfFactorGrads", "TfField", "TfMarchIO", "TfPeBlock", "TfShade", "TfShadeGrads"):
+    for cname in ("TfFactors", "TfFactorGrads", "TfField", "TfMarchIO", "TfPeBlock", "TfShade", "TfShadeGrads",
+                  "TfAdamSeg", "TfAdamJob"):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), text, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         decl = []
@@ -42,7 +43,7 @@ def test_ctypes_structs_match_header_field_order(recon):
             if not stmt:
                 continue
             for part in stmt.split(","):
-                m = re.search(r"([A-Za-z_][A-Za-z0-9_]*)\s*(\[\d+\])?\s*$", part.strip())
+                m = re.search(r"([A-Za-z_][A-Za-z0-9_]*)\s*(\[\w+\])?\s*$", part.strip())
                 decl.append(m.group(1))
         fields = [f[0] for f in getattr(recon._hip, cname)._fields_]
         assert fields == decl, (cname, fields, decl)

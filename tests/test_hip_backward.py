@@ -99,3 +99,110 @@ def test_graphed_adam_training_reduces_loss(recon):
     torch.manual_seed(0)
     losses = [gs.step(rays, target).item() for _ in range(8)]
     assert gs.graph is not None and losses[-1] < losses[0], losses
+
+
+def _same_trajectory(finals, init, losses):
+    """Two runs of the same optimisation.  The packed sample order (atomic reservations) and with it every fp32
+    summation order varies from run to run, and Adam turns the sign of a rounding-noise gradient into a full +-lr
+    step, so single weights may differ: compare the loss curves, the strongly driven tensors element-wise
+    against the distance moved, and the MLP weights in the L2 sense."""
+    for a, b in zip(*losses):
+        assert abs(a - b) <= 2e-3 * abs(a), losses
+    for k in finals[0]:
+        d0 = finals[0][k] - init[k]
+        gap = finals[0][k] - finals[1][k]
+        if k.startswith("renderModule"):
+            assert gap.norm().item() <= 0.35 * d0.norm().item() + 1e-7, (k, gap.norm().item(), d0.norm().item())
+        else:
+            assert gap.abs().max().item() <= 0.05 * d0.abs().max().item() + 1e-7, k
+
+
+@pytest.mark.gpu
+def test_split_graph_step_equals_single_graph_step(recon):
+    """The data-parallel form (backward graph | gradient all-reduce | optimizer graph) takes the same steps."""
+    c = Case("vm_cubic_train")
+    dev = "cuda:0"
+    rays, target = c.rays.to(dev), torch.from_numpy(c.expect("grad/target")).to(dev)
+    finals, losses = [], []
+    for split in (False, True):
+        model = build_model(recon, c, dev)
+        init = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        opt = torch.optim.Adam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), fused=True, capturable=True)
+        gs = recon.GraphedTrainStep(model, opt, rays.shape[0], -1, warmup=1, split=split)
+        torch.manual_seed(0)
+        losses.append([gs.step(rays, target).item() for _ in range(6)])
+        assert gs.graph is not None and (gs.graph_opt is not None) == split
+        finals.append({k: v.detach().clone() for k, v in model.state_dict().items()})
+    _same_trajectory(finals, init, losses)
+
+
+@pytest.mark.gpu
+def test_fused_adam_matches_torch_adam(recon):
+    """tf_adam_step against torch.optim.Adam on the same gradients: dense, channel-last and odd-sized tensors, two
+    parameter groups, a learning rate that decays every step (train.py:391-392)."""
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(3)
+    shapes = [(1, 16, 37, 41), (1, 48, 33, 1), (27, 144), (128, 150), (128,), (3,), (5, 7)]
+    def make():
+        ps = []
+        for i, s in enumerate(shapes):
+            t = torch.randn(*s, generator=torch.Generator().manual_seed(10 + i)).to(dev)
+            if len(s) == 4:
+                t = recon.channel_last_param(t).data
+            ps.append(torch.nn.Parameter(t))
+        return ps
+    pa, pb = make(), make()
+    groups = lambda ps: [{'params': ps[:2], 'lr': 0.02}, {'params': ps[2:], 'lr': 1e-3}]
+    oa = torch.optim.Adam(groups(pa), betas=(0.9, 0.99))
+    ob = recon.FusedAdam(groups(pb), betas=(0.9, 0.99))
+    for it in range(7):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=g).to(dev) * (10.0 ** (it % 3 - 2))
+            if it == 3:
+                gr = gr * (torch.rand(a.shape, generator=g).to(dev) > 0.5)          # exact zeros
+            a.grad = torch.empty_like(a).copy_(gr)          # empty_like keeps the (channel-last) strides
+            b.grad = torch.empty_like(b).copy_(gr)
+        oa.step()
+        ob.step()
+        for grp in oa.param_groups + ob.param_groups:
+            grp['lr'] = grp['lr'] * 0.9
+    for a, b, s in zip(pa, pb, shapes):
+        assert a.stride() == b.stride()
+        err = (a - b).abs().max().item()
+        assert err <= 2e-6 * max(1.0, a.abs().max().item()), (s, err)
+        sa, sb = oa.state[a], ob.state[b]
+        for key in ('exp_avg', 'exp_avg_sq'):       # sums of terms of either sign: bound by the tensor's scale
+            scale = sa[key].abs().max().item()
+            assert (sa[key] - sb[key]).abs().max().item() <= 2e-6 * scale, (s, key)
+    assert float(ob.state[pb[0]]['step']) == 7
+
+
+@pytest.mark.gpu
+def test_graphed_fused_adam_follows_lr_schedule(recon):
+    """GraphedTrainStep + FusedAdam under a decaying learning rate takes the steps of the eager loop."""
+    c = Case("vm_cubic_train")
+    dev = "cuda:0"
+    rays, target = c.rays.to(dev), torch.from_numpy(c.expect("grad/target")).to(dev)
+    finals, losses = [], []
+    for graphed in (False, True):
+        model = build_model(recon, c, dev)
+        init = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        opt = recon.FusedAdam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+        gs = recon.GraphedTrainStep(model, opt, rays.shape[0], -1, warmup=1) if graphed else None
+        torch.manual_seed(0)
+        losses.append([])
+        for it in range(6):
+            if graphed:
+                loss = gs.step(rays, target)
+            else:
+                rgb, _, _ = model(rays, None, white_bg=True, is_train=True)
+                loss = torch.mean((rgb - target) ** 2)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+            losses[-1].append(loss.item())
+            for grp in opt.param_groups:
+                grp['lr'] = grp['lr'] * 0.7
+        assert not graphed or gs.graph is not None
+        finals.append({k: v.detach().clone() for k, v in model.state_dict().items()})
+    _same_trajectory(finals, init, losses)

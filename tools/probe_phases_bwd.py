@@ -18,6 +18,8 @@ perm = torch.randperm(rays.shape[0], generator=torch.Generator().manual_seed(1))
 batches = [rays[perm[i * R:(i + 1) * R]].contiguous() for i in range(4)]
 lib = recon_amd._hip.lib()
 out = (ctypes.c_ulonglong * 16)()
+if len(sys.argv) > 1:
+    lib.tf_debug_set_bwd_wgs(int(sys.argv[1]))
 tgt = torch.rand(R, 3, device=dev)
 for rep in range(2):
     for b in batches:
@@ -27,8 +29,9 @@ for rep in range(2):
         loss.backward()
     torch.cuda.synchronize()
     lib.tf_debug_phase_cycles_bwd(out, 1)
-names = ["fwd-recompute", "dW3/dZ2 pass", "dW2", "dH1->dZ1", "db1+dW1", "featcopy+dX", "dfeat+dB+dV", "dV store"]
-tot = sum(out[i] for i in range(8))
+names = ["info+out layer", "dW3/dZ2 pass", "dW2", "dH1->dZ1", "db1+dW1", "featcopy+dX", "dfeat+dB+dV", "dV store",
+         "gather", "basis", "PE", "layer1", "layer2"]
+tot = sum(out[i] for i in range(13))
 ntile = sum((int(c) + 63) // 64 for c in model.last["ws"].counters2d[:, 0].tolist())
 print("tiles in last batch", ntile)
 for i, n in enumerate(names):
