@@ -17,10 +17,11 @@ from .field import _stream, is_channel_last
 N_REP = 64   # replicas of the line-gradient tensors (TfFactorGrads.n_rep)
 
 
-def _grad_buffers(named):
-    """One zero-filled allocation: [line gradients | all other gradients | N_REP replicas of the line block].
-    The kernels scatter line gradients into the replicas; tf_reduce_replicas folds them into the head of
-    the buffer, so flat[:grad_len] is every parameter gradient of the step, contiguous (one all-reduce)."""
+def _grad_buffers(named, n_rep=N_REP):
+    """One zero-filled allocation: [line gradients | all other gradients | n_rep replicas of the line block].
+    The direct-scatter kernels spread line-gradient atomics over the replicas; tf_reduce_replicas folds them
+    into the head of the buffer, so flat[:grad_len] is every parameter gradient of the step, contiguous (one
+    all-reduce).  The binned scatter flushes each line bucket once per work item and needs no replicas."""
     named = sorted(named, key=lambda kv: 0 if '_line.' in kv[0] else 1)
     offs, total, line_len = {}, 0, 0
     for name, p in named:
@@ -28,7 +29,7 @@ def _grad_buffers(named):
         total += (p.numel() + 63) // 64 * 64
         if '_line.' in name:
             line_len = total
-    flat = torch.zeros(total + N_REP * line_len, dtype=torch.float32, device=named[0][1].device)
+    flat = torch.zeros(total + n_rep * line_len, dtype=torch.float32, device=named[0][1].device)
     views = {}
     for name, p in named:
         chunk = flat[offs[name]:offs[name] + p.numel()]
@@ -64,22 +65,22 @@ class _RenderFn(torch.autograd.Function):
         ws = c['ws']
         st = _stream()
         named = list(zip(names, ctx.params))
-        grads, flat, offs, grad_len, line_len = _grad_buffers(named)
+        binned = ws.binned_cfg is not None
+        n_rep = 0 if binned else N_REP
+        grads, flat, offs, grad_len, line_len = _grad_buffers(named, n_rep)
         model.grad_flat = flat[:grad_len]   # every gradient of this step, one contiguous buffer (parallel.py)
         g = g_rgb.detach().to(torch.float32).contiguous()
         cp = model._is_cp()
-        rep0 = flat.data_ptr() + 4 * grad_len          # replica 0 of the line block
+        rep0 = flat.data_ptr() + 4 * (grad_len if n_rep else 0)   # replica 0 of the line block (binned: the head itself)
 
         dg = H.TfFactorGrads()
         ag = H.TfFactorGrads()
         for fg, kind in ((dg, 'density'), (ag, 'app')):
-            fg.n_rep, fg.rep_stride = N_REP, line_len
+            fg.n_rep, fg.rep_stride = max(n_rep, 1), line_len
             for i in range(3):
                 if not cp:
                     fg.plane[i] = grads[f'{kind}_plane.{i}'].data_ptr()
                 fg.line[i] = rep0 + 4 * offs[f'{kind}_line.{i}']
-        binned = ws.binned_cfg is not None
-
         def bin_job(factors, fgrads, slot, xyz, grad, grad_ld, part):
             nkeys = ws.binned_cfg[0 if part == "density" else 1]
             nmax = max(ws.binned_cfg[0], ws.binned_cfg[1])
@@ -113,7 +114,8 @@ class _RenderFn(torch.autograd.Function):
                      ws.grad_rgb.data_ptr(), C.byref(sg), st)
         if binned:
             bin_job(c['shade'].app, ag, 0, ws.app_xyz, ws.dv, model._n_app_total(), "app")
-        model._timed("tf_reduce_replicas", lib.tf_reduce_replicas, rep0, N_REP, line_len, line_len, flat.data_ptr(), st)
+        if n_rep:
+            model._timed("tf_reduce_replicas", lib.tf_reduce_replicas, rep0, n_rep, line_len, line_len, flat.data_ptr(), st)
         out = tuple(grads[n] if p.requires_grad else None for n, p in named)
         ws.busy = False     # stream order: the next forward that takes this workspace runs after these kernels
         ctx.c = None

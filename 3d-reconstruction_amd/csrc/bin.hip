@@ -24,6 +24,7 @@ constexpr int kCG = 16;   // components per key: wide decompositions are split i
 
 struct KeyMap {
     int T, LB;
+    int tsh, lsh;             // log2(T), log2(LB): tile and bucket sizes are powers of two (no integer divides per entry)
     int ntx[3], ptiles[3], lbuckets[3], ncg[3];
     int plane_base[3], line_base[3];
     int nkeys, keys_per_entry;
@@ -33,6 +34,9 @@ __host__ __device__ inline KeyMap make_keymap(const int grid[3], const int n_com
     KeyMap K;
     K.T = T;
     K.LB = LB;
+    K.tsh = K.lsh = 0;
+    while ((1 << K.tsh) < T) ++K.tsh;
+    while ((1 << K.lsh) < LB) ++K.lsh;
     int run = 0, kpe = 0;
     for (int i = 0; i < 3; ++i) {
         const int W = grid[i == 2 ? 1 : 0], H = grid[i == 0 ? 1 : 2];
@@ -73,8 +77,8 @@ __device__ __forceinline__ void sample_keys(const KeyMap& K, const int grid[3], 
     for (int i = 0; i < 3; ++i) {
         const int x = min(max(g.x0[i], 0), grid[mat0(i)] - 1), y = min(max(g.y0[i], 0), grid[mat1(i)] - 1);
         const int l = min(max(g.l0[i], 0), grid[vecm(i)] - 1);
-        keys[i] = K.plane_base[i] + (y / K.T) * K.ntx[i] + x / K.T;
-        keys[3 + i] = K.line_base[i] + l / K.LB;
+        keys[i] = K.plane_base[i] + (y >> K.tsh) * K.ntx[i] + (x >> K.tsh);
+        keys[3 + i] = K.line_base[i] + (l >> K.lsh);
     }
 }
 #define TF_FOR_EACH_KEY(K, keys, key, BODY)                                   \
@@ -84,7 +88,7 @@ __device__ __forceinline__ void sample_keys(const KeyMap& K, const int grid[3], 
             { const int key = (keys)[3 + _i] + _g * (K).lbuckets[_i]; BODY; } \
         }
 
-constexpr int kSlices = 8;   // workgroups per entry shard in the count / fill passes
+constexpr int kSlices = 4;   // workgroups per entry shard in the count / fill passes
 
 // (a kernel rather than hipMemsetAsync: the memset issued from this library was not replayed by a captured
 // hipGraph, which left the histogram un-zeroed on the second replay)
@@ -113,45 +117,90 @@ __global__ __launch_bounds__(256) void bin_count_kernel(const TfBinJob J, const 
         if (lh[i]) atomicAdd(&J.hist[i], lh[i]);
 }
 
-// offsets[] = exclusive prefix of hist[], chunk_off[] = exclusive prefix of ceil(hist/chunk); cursor = offsets
-__global__ __launch_bounds__(1024) void bin_scan_kernel(const TfBinJob J, int nkeys) {
-    __shared__ int part[1024], part2[1024];
+// offsets[] = exclusive prefix of hist[], chunk_off[] = exclusive prefix of ceil(hist/chunk); cursor = offsets.
+// One workgroup (the job has <= 18000 keys): the histogram is pulled into LDS with coalesced loads first — every
+// later pass touches LDS only (per-thread strided global reads made this kernel a chain of memory latencies).
+__global__ __launch_bounds__(1024) void bin_scan_kernel(const TfBinJob J, int nkeys, int csh /* log2(J.chunk) */) {
+    extern __shared__ int sh[];                 // hist copy [nkeys]
+    __shared__ int part[16], part2[16];
     const int tid = threadIdx.x;
-    const int per = (nkeys + 1023) / 1024;
-    int s = 0, s2 = 0;
-    for (int i = tid * per; i < min(nkeys, (tid + 1) * per); ++i) {
-        s += J.hist[i];
-        s2 += (J.hist[i] + J.chunk - 1) / J.chunk;
-    }
-    part[tid] = s;
-    part2[tid] = s2;
+    for (int i = tid; i < nkeys; i += 1024) sh[i] = J.hist[i];
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int a = tid >= o ? part[tid - o] : 0, b = tid >= o ? part2[tid - o] : 0;
-        __syncthreads();
-        part[tid] += a;
-        part2[tid] += b;
-        __syncthreads();
+    const int per = (nkeys + 1023) / 1024;
+    const int lo = tid * per, hi = min(nkeys, (tid + 1) * per);
+    int s = 0, s2 = 0;
+    for (int i = lo; i < hi; ++i) {
+        s += sh[i];
+        s2 += (sh[i] + J.chunk - 1) >> csh;
     }
-    int run = part[tid] - s, run2 = part2[tid] - s2;
-    for (int i = tid * per; i < min(nkeys, (tid + 1) * per); ++i) {
-        J.offsets[i] = run;
-        J.cursor[i] = run;
-        J.chunk_off[i] = run2;
-        run += J.hist[i];
-        run2 += (J.hist[i] + J.chunk - 1) / J.chunk;
+    // inclusive scan over the 1024 threads: shuffles inside each wave, then the 16 wave totals
+    int v = s, v2 = s2;
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int a = __shfl_up(v, o, 64), b = __shfl_up(v2, o, 64);
+        if (lane >= o) {
+            v += a;
+            v2 += b;
+        }
     }
-    if (tid == 1023) {
-        J.offsets[nkeys] = part[1023];
-        J.chunk_off[nkeys] = part2[1023];
+    if (lane == 63) {
+        part[wv] = v;
+        part2[wv] = v2;
     }
+    __syncthreads();
+    int wbase = 0, wbase2 = 0, tot = 0, tot2 = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int a = part[w], b = part2[w];
+        if (w < wv) {
+            wbase += a;
+            wbase2 += b;
+        }
+        tot += a;
+        tot2 += b;
+    }
+    v += wbase;
+    v2 += wbase2;
+    // The per-thread key ranges are contiguous, so writing the prefixes straight to global memory would be one
+    // cache line per lane and store; they go to LDS (in place of the histogram) and leave with coalesced stores.
     // item table: work item -> key (chunk index = item - chunk_off[key]); lives behind chunk_off[]
     int* items = J.chunk_off + nkeys + 1;
-    run2 = part2[tid] - s2;
-    for (int i = tid * per; i < min(nkeys, (tid + 1) * per); ++i) {
-        const int nc = (J.hist[i] + J.chunk - 1) / J.chunk;
-        for (int c = 0; c < nc; ++c) items[run2 + c] = i;
-        run2 += nc;
+    constexpr int kPer = 18;                     // ceil(18000 / 1024): per-thread histogram slice in registers
+    int h[kPer];
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) h[q] = lo + q < hi ? sh[lo + q] : 0;
+    int run = v - s, run2 = v2 - s2;
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        if (lo + q < hi) {
+            sh[lo + q] = run;
+            const int nc = (h[q] + J.chunk - 1) >> csh;
+            for (int c = 0; c < nc; ++c) items[run2 + c] = lo + q;
+            run += h[q];
+            run2 += nc;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < nkeys; i += 1024) {
+        const int o = sh[i];
+        J.offsets[i] = o;
+        J.cursor[i] = o;
+    }
+    __syncthreads();
+    run2 = v2 - s2;
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        if (lo + q < hi) {
+            sh[lo + q] = run2;
+            run2 += (h[q] + J.chunk - 1) >> csh;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < nkeys; i += 1024) J.chunk_off[i] = sh[i];
+    if (tid == 1023) {
+        J.offsets[nkeys] = tot;
+        J.chunk_off[nkeys] = tot2;
     }
 }
 
@@ -189,6 +238,9 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(const TfBinJob J, const K
     }
 }
 
+// x / d for 0 <= x < 2^20 and small d via a float reciprocal (an emulated integer divide is ~40 instructions)
+__device__ __forceinline__ int fdiv(int x, float inv_d) { return (int)(((float)x + 0.5f) * inv_d); }
+
 __device__ __forceinline__ float entry_grad(const TfBinJob& J, int e, int ch) {
     return J.grad_ld ? J.grad[(size_t)e * J.grad_ld + ch] : J.grad[e];
 }
@@ -209,18 +261,22 @@ __host__ __device__ inline int lane_group(int c) { return c <= 16 ? 16 : (c <= 3
 //          accumulation block (LDS float atomics measured ~100 cycles per wave-instruction, a plain RMW is 3 short
 //          LDS ops; lanes of one instruction never collide and the LDS pipe is in order).  No global access.
 //   The four private blocks are summed when the work item is flushed.
-__global__ __launch_bounds__(256) void bin_scatter_kernel(const TfBinJob J, const KeyMap K, int ER, int cmax) {
+__global__ __launch_bounds__(256, 5) void bin_scatter_kernel(const TfBinJob J, const KeyMap K, int ER, int cmax) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wstride = ER * (cmax + 8);
-    float* pre = smem + wave * wstride;            // [ER][C]
-    float* meta = pre + ER * cmax;                 // [ER][8]: cell (int), w00, w01, w10, w11 | cell, w0, w1
-    float* blk0 = smem + 4 * wstride;              // 4 private accumulation blocks (one per wave)
     const int total = J.chunk_off[K.nkeys];
     const size_t rep = (size_t)(blockIdx.x % J.grads.n_rep) * J.grads.rep_stride;
     TF_T0();
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
         TF_MARK(7);
+        // per-thread coordinates from an opaque copy of the thread id: nothing derived from it is hoisted out of the
+        // work-item loop, which keeps the kernel at 5 waves per SIMD without scratch
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int wave = tid >> 6, lane = tid & 63;
+        float* pre = smem + wave * wstride;            // [ER][C]
+        float* meta = pre + ER * cmax;                 // [ER][8]: cell (int), w00, w01, w10, w11 | cell, w0, w1
+        float* blk0 = smem + 4 * wstride;              // 4 private accumulation blocks (one per wave)
         const int key = J.chunk_off[K.nkeys + 1 + w], chunk = w - J.chunk_off[key];
         const int beg = J.offsets[key] + chunk * J.chunk, end = min(J.offsets[key + 1], beg + J.chunk);
         const bool is_line = key >= K.line_base[0];
@@ -323,12 +379,14 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const TfBinJob J, cons
         __syncthreads();
         TF_MARK(3);
         // ---------------- flush the block: contiguous rows of (T+1) x C (or C) floats
+        const float invC = 1.f / (float)C, invT1 = 1.f / (float)T1;
         if (!is_line) {
             float* gp = J.grads.plane[i];
             for (int q = tid; q < nblk; q += 256) {
                 const float v = (blk0[q] + blk0[nblk + q]) + (blk0[2 * nblk + q] + blk0[3 * nblk + q]);
                 if (v == 0.f) continue;
-                const int c = q % C, cell = q / C, yy = tyb + cell / T1, xx = txb + cell % T1;
+                const int cell = fdiv(q, invC), c = q - cell * C, cy = fdiv(cell, invT1);
+                const int yy = tyb + cy, xx = txb + cell - cy * T1;
                 if (yy < Hh && xx < W) atomicAdd(gp + ((size_t)yy * W + xx) * CF + c0 + c, v);
             }
         } else {
@@ -336,7 +394,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const TfBinJob J, cons
             for (int q = tid; q < nblk; q += 256) {
                 const float v = (blk0[q] + blk0[nblk + q]) + (blk0[2 * nblk + q] + blk0[3 * nblk + q]);
                 if (v == 0.f) continue;
-                const int c = q % C, ent = lb0 + q / C;
+                const int eq = fdiv(q, invC), c = q - eq * C, ent = lb0 + eq;
                 if (ent < Gl) atomicAdd(gl + (size_t)ent * CF + c0 + c, v);
             }
         }
@@ -374,6 +432,10 @@ int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     const KeyMap K = make_keymap(job->grid, job->factors.n_comp, job->tile, job->bucket);
     if (K.nkeys != job->nkeys || K.nkeys > 18000) return (int)hipErrorInvalidValue;   // 2 LDS ints per key in K3
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    if (!pow2(job->tile) || !pow2(job->bucket) || !pow2(job->chunk)) return (int)hipErrorInvalidValue;
+    int csh = 0;
+    while ((1 << csh) < job->chunk) ++csh;
     int cmax = job->factors.n_comp[0];
     for (int i = 1; i < 3; ++i) cmax = job->factors.n_comp[i] > cmax ? job->factors.n_comp[i] : cmax;
     cmax = cmax > kCG ? kCG : cmax;
@@ -390,7 +452,10 @@ int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream) {
                             (int)(sizeof(int) * K.nkeys));
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(bin_count_kernel, dim3(TF_N_SHARDS * kSlices), dim3(256), sizeof(int) * K.nkeys, st, *job, K);
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, *job, K.nkeys);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(int) * K.nkeys));
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), sizeof(int) * K.nkeys, st, *job, K.nkeys, csh);
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(sizeof(int) * 2 * K.nkeys));
     if (e != hipSuccess) return (int)e;

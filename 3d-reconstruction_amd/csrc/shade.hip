@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void shade_forward_kernel(const TfShade S, con
             f32x4 acc[NB][1];
 #pragma unroll
             for (int i = 0; i < NB; ++i) acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            mma_block<NB, 1>(S.basis, kpad16(S.n_app_total), 0, regA, L.sv, wave * 16, kpad16(S.n_app_total) / 16, acc);
+            mma_block<NB, 1>(S.basis, kpad16(S.n_app_total), 0, regA, L.sv, wave * 16, kpad16(S.n_app_total) / 16, acc, lane);
             const int smp = wave * 16 + (lane & 15), g = lane >> 4;
 #pragma unroll
             for (int i = 0; i < NB; ++i)
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void shade_forward_kernel(const TfShade S, con
             for (int i = 0; i < NF; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            mma_block<NF, 4>(S.w1, kpad16(S.in_c), 16 * NF * wave, regB, L.sx, 0, kpad16(S.in_c) / 16, acc);
+            mma_block<NF, 4>(S.w1, kpad16(S.in_c), 16 * NF * wave, regB, L.sx, 0, kpad16(S.in_c) / 16, acc, lane);
             const int c = lane & 15, g = lane >> 4;
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void shade_forward_kernel(const TfShade S, con
             for (int i = 0; i < NF; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            mma_block<NF, 4>(S.w2, kpad16(FC), 16 * NF * wave, regA, L.sh, 0, FC / 16, acc);
+            mma_block<NF, 4>(S.w2, kpad16(FC), 16 * NF * wave, regA, L.sh, 0, FC / 16, acc, lane);
             const int c = lane & 15, g = lane >> 4;
 #pragma unroll
             for (int i = 0; i < NF; ++i) {

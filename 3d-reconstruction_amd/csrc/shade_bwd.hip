@@ -37,8 +37,8 @@ __device__ __forceinline__ f32x4 ldfrag(const float* p, int ld, int idx, int k) 
 // acc[i][j] += sum_k A(a_base+16i + r, k) * B(b_base+16j + r, k), k in [0, 16*kgroups)
 template <int NA, int NBT, int AM, int BM>
 __device__ __forceinline__ void mma_gen(const float* A, int lda, int a_base, const float* B, int ldb, int b_base,
-                                        int kgroups, f32x4 (&acc)[NA][NBT]) {
-    const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
+                                        int kgroups, f32x4 (&acc)[NA][NBT], int lane) {
+    const int r = lane & 15, kq = lane >> 4;
 #pragma unroll 1
     for (int kg = 0; kg < kgroups; ++kg) {
         const int k = 16 * kg + 4 * kq;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
     // per-sample tile info of thread tid < 64, loaded for the NEXT tile while the current one is processed
     int nx_ray = 0;
     float nx_x[3] = {0.f, 0.f, 0.f}, nx_v[3] = {0.f, 0.f, 0.f};
-    auto fetch_info = [&](int s0_, int n_) {
+    auto fetch_info = [&](int s0_, int n_, int tid) {   // tid passed in: the tile loop hands its opaque copy
         nx_ray = 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) nx_x[a] = nx_v[a] = 0.f;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
     };
     {
         int s1, n1;
-        if (tid < M && locate_tile(src, pre, (int)blockIdx.x, s1, n1)) fetch_info(s1, n1);
+        if (tid < M && locate_tile(src, pre, (int)blockIdx.x, s1, n1)) fetch_info(s1, n1, tid);
     }
     const bool quads = vm_quads_ok(S);
 
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         lds_barrier();
         {
             int s1, n1;
-            if (tid < M && locate_tile(src, pre, t + (int)gridDim.x, s1, n1)) fetch_info(s1, n1);
+            if (tid < M && locate_tile(src, pre, t + (int)gridDim.x, s1, n1)) fetch_info(s1, n1, tid);
         }
 
         // ================= forward recompute =================
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
             const int bf = wave >> 2, bs = wave & 3;
             f32x4 acc[1][1];
             zero_acc(acc);
-            mma_block<1, 1>(S.basis, kpB, 16 * bf, V, L.sv, 16 * bs, ktB, acc);
+            mma_block<1, 1>(S.basis, kpB, 16 * bf, V, L.sv, 16 * bs, ktB, acc, lane);
             const int smp = 16 * bs + lc;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         {   // layer 1 -> H1
             f32x4 acc[1][NSW];
             zero_acc(acc);
-            mma_block<1, NSW>(S.w1, kp1, 16 * my_ft, X, L.sx, s_base, kt1, acc);
+            mma_block<1, NSW>(S.w1, kp1, 16 * my_ft, X, L.sx, s_base, kt1, acc, lane);
             const int f = 16 * my_ft + 4 * lg;
             const f32x4 bias = *reinterpret_cast<const f32x4*>(S.b1 + f);
 #pragma unroll
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         {   // layer 2 -> H2
             f32x4 acc[1][NSW];
             zero_acc(acc);
-            mma_block<1, NSW>(S.w2, kpad16(FC), 16 * my_ft, H1, L.sh, s_base, FC / 16, acc);
+            mma_block<1, NSW>(S.w2, kpad16(FC), 16 * my_ft, H1, L.sh, s_base, FC / 16, acc, lane);
             const int f = 16 * my_ft + 4 * lg;
             const f32x4 bias = *reinterpret_cast<const f32x4*>(S.b2 + f);
 #pragma unroll
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                 run[j] = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(sp);
             }
             zero_acc(aW2);
-            mma_gen<1, NW2, COL, COL>(H2, L.sh, 16 * my_ft, H1, L.sh, 16 * NW2 * my_sg, M / 16, aW2);
+            mma_gen<1, NW2, COL, COL>(H2, L.sh, 16 * my_ft, H1, L.sh, 16 * NW2 * my_sg, M / 16, aW2, lane);
 #pragma unroll
             for (int j = 0; j < NW2; ++j)
                 *reinterpret_cast<f32x4*>(slabW2 + ((size_t)(my_ft * FT + NW2 * my_sg + j) * 64 + lane) * 4) = aW2[0][j] + run[j];
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         {   // dH1[f1][s] = sum_f2 W2[f2][f1] dZ2[s][f2];  dZ1 = dH1 . [H1 > 0] written in place of H1
             f32x4 acc[1][NSW];
             zero_acc(acc);
-            mma_block<1, NSW>(S.w2t, FC, 16 * my_ft, H2, L.sh, s_base, FC / 16, acc);
+            mma_block<1, NSW>(S.w2t, FC, 16 * my_ft, H2, L.sh, s_base, FC / 16, acc, lane);
             const int f = 16 * my_ft + 4 * lg;
 #pragma unroll
             for (int j = 0; j < NSW; ++j) {
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         for (int kt = wave; kt < kt1; kt += NW) {
             f32x4 acc[1][4];
             zero_acc(acc);
-            mma_block<1, 4>(S.w1t, FC, 16 * kt, H1, L.sh, 0, FC / 16, acc);
+            mma_block<1, 4>(S.w1t, FC, 16 * kt, H1, L.sh, 0, FC / 16, acc, lane);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 *reinterpret_cast<f32x4*>(X + (16 * j + lc) * L.sx + 16 * kt + 4 * lg) = acc[0][j];
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                 run[i] = first ? (f32x4){0.f, 0.f, 0.f, 0.f}
                                : *reinterpret_cast<const f32x4*>(slabB + ((size_t)(i * ktB + ct) * 64 + lane) * 4);
             zero_acc(one);
-            mma_gen<NB, 1, COL, COL>(Fd, L.sf, 0, V, L.sv, 16 * ct, M / 16, one);
+            mma_gen<NB, 1, COL, COL>(Fd, L.sf, 0, V, L.sv, 16 * ct, M / 16, one, lane);
 #pragma unroll
             for (int i = 0; i < NB; ++i)
                 *reinterpret_cast<f32x4*>(slabB + ((size_t)(i * ktB + ct) * 64 + lane) * 4) = one[i][0] + run[i];
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         for (int ct = wave; ct < ktB; ct += NW) {
             f32x4 acc[1][4];
             zero_acc(acc);
-            mma_gen<1, 4, COL, ROW>(S.basis, kpB, 16 * ct, Fd, L.sf, 0, NB, acc);
+            mma_gen<1, 4, COL, ROW>(S.basis, kpB, 16 * ct, Fd, L.sf, 0, NB, acc, lane);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 *reinterpret_cast<f32x4*>(V + (16 * j + lc) * L.sv + 16 * ct + 4 * lg) = acc[0][j];
@@ -500,13 +500,15 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
 
     // ================= the per-feature scalars (the GEMM gradients are in the slab) =================
     {
-        const int pf = tid % FC;
+        int tid2 = threadIdx.x;
+        asm volatile("" : "+v"(tid2));      // keeps these addresses from being computed (and held) before the tile loop
+        const int pf = tid2 % FC;
         atomicAdd(G.w3 + pf, aW3[0]);
         atomicAdd(G.w3 + FC + pf, aW3[1]);
         atomicAdd(G.w3 + 2 * FC + pf, aW3[2]);
         atomicAdd(G.b2 + pf, ab2);
         atomicAdd(G.b1 + pf, ab1);
-        if (tid < 3) atomicAdd(G.b3 + tid, ab3);
+        if (tid2 < 3) atomicAdd(G.b3 + tid2, ab3);
     }
 }
 

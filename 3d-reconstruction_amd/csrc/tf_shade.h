@@ -36,8 +36,8 @@ __host__ __device__ inline ShadeLds shade_lds(const TfShade& S) {
 // element e of both, i.e. k = 16kg+4kq+e on both operands.  D: row(feature) = 4*(lane>>4)+reg, col(sample) = lane&15.
 template <int NF, int NS>
 __device__ __forceinline__ void mma_block(const float* __restrict__ Wg, int ldw, int f_base, const float* Xs, int ldx,
-                                          int s_base, int kgroups, f32x4 (&acc)[NF][NS]) {
-    const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
+                                          int s_base, int kgroups, f32x4 (&acc)[NF][NS], int lane) {
+    const int r = lane & 15, kq = lane >> 4;
     const float* wp = Wg + (size_t)(f_base + r) * ldw + 4 * kq;
     const float* xp = Xs + (s_base + r) * ldx + 4 * kq;
 #pragma unroll 2
