@@ -49,8 +49,7 @@ class _RenderFn(torch.autograd.Function):
         ctx.model, ctx.c, ctx.names = model, c, names
         ctx.versions = [p._version for p in params]
         ctx.params = params
-        rgb_map = ws.rgb_map.view(ws.R, 3).clone()
-        depth = ws.depth.clone()
+        rgb_map, depth = c.pop('rgb_map'), c.pop('depth')     # fresh tensors written by the kernels
         nvalid = ws.counters2d[:, 0].sum()
         ctx.mark_non_differentiable(depth, nvalid)
         return rgb_map, depth, nvalid

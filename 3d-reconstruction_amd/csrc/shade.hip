@@ -1,8 +1,8 @@
 // shade.hip — appearance lookup + shading head on the packed app list.   gfx950, wave64, fp32 MFMA.
 //
-// A 256-thread workgroup (4 waves) shades one tile of TF_TILE = 64 samples:
-//   1. gather: 4 lanes per sample read each bilinear tap of the channel-last appearance planes/lines as
-//      contiguous 16-B pieces (64 B per 4-lane group per tap) and write the plane*line products
+// A 512-thread workgroup (8 waves) shades one tile of TF_TILE = 64 samples, two workgroups per CU:
+//   1. gather: 8 lanes per sample read each bilinear tap of the channel-last appearance planes/lines as
+//      contiguous 16-B pieces (128 B per 8-lane group per tap) and write the plane*line products
 //      (sum n_comp wide) to an LDS tile V[64][.]                      tensoRF.py:238-260 / :394-410
 //   2. basis_mat: feat^T = B . V^T on v_mfma_f32_16x16x4_f32 (exact fp32)  tensoRF.py:263
 //   3. MLP input: [feat, view, PE blocks] built in LDS               mlp.py:8-13, 41-66
@@ -15,21 +15,28 @@ using namespace tf;
 
 namespace {
 
-// NF = feature_c / 64 (feature tiles per wave), NB = ceil(app_dim/16) (basis feature tiles).
-template <int NF, int NB>
-__global__ __launch_bounds__(256) void shade_forward_kernel(const TfShade S, const TileSrc src, float* __restrict__ rgb_out,
-                                                            float* __restrict__ feat_out) {
+// FT = feature_c / 16 hidden feature tiles (4, 8 or 16), NB = ceil(app_dim/16) basis feature tiles.
+// 512 threads = 8 waves shade one 64-sample tile; two workgroups share a CU (81,680 B of LDS each), i.e. 4 waves per
+// SIMD (<= 128 VGPRs).  A launch has only ~5 tiles per CU: the chain of dependent phases of one tile is spread over
+// 8 waves, and the two resident workgroups fill each other's barrier and memory waits.  (Measured: starting half of
+// the workgroups half a tile late to break lockstep changed nothing; issuing all taps of a sample at once made the
+// gather slower — it is bound by the CU's fetch rate from the Infinity Cache, ~11-18 B/cycle/CU.)
+// Wave w: feature tiles NFW*(w % FG) .. +NFW, sample tiles NSW*(w / FG) .. +NSW  (FG = 8 / SG feature groups).
+template <int FT, int NB>
+__global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, const TileSrc src, float* __restrict__ rgb_out,
+                                                               float* __restrict__ feat_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // the only LDS object (16-B aligned base)
+    constexpr int NT = 512, NW = 8, SG = FT < NW ? NW / FT : 1, FG = NW / SG, NFW = FT / FG, NSW = 4 / SG;
     const ShadeLds L = shade_lds(S);
     int* pre = reinterpret_cast<int*>(lds + L.offPre);
     float* regA = lds + L.offA;   // V, then H1
     float* regB = lds + L.offB;   // X, then H2
     float* ixyz = lds + L.offInfo;           // [64][3]
     float* iview = lds + L.offInfo + 3 * M;  // [64][3]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid0 = threadIdx.x;
 
     if (src.counters) {   // tile prefix over shards (every workgroup computes the same table)
-        if (tid == 0) {
+        if (tid0 == 0) {
             int run = 0;
             for (int g = 0; g < TF_N_SHARDS; ++g) {
                 pre[g] = run;
@@ -46,13 +53,21 @@ __global__ __launch_bounds__(256) void shade_forward_kernel(const TfShade S, con
     // third round.  Direct mode (point lists) keeps the static stride.
     int* ticket = src.counters ? const_cast<int*>(src.counters) + TF_TICKET_SLOT : nullptr;
     int* tbox = reinterpret_cast<int*>(lds + L.offPre) + TF_N_SHARDS + 2;
-    if (ticket && tid == 0) tbox[0] = atomicAdd(ticket, 1);
+    if (ticket && tid0 == 0) tbox[0] = atomicAdd(ticket, 1);
     __syncthreads();
     for (int t = ticket ? tbox[0] : (int)blockIdx.x;; t = ticket ? tbox[0] : t + (int)gridDim.x) {
         int s0, n;
         if (!locate_tile(src, pre, t, s0, n)) break;
+        // thread coordinates from an opaque copy of the thread id, so that no per-thread address of a later phase is
+        // computed (and kept in registers) outside the tile loop: the kernel has 128 VGPRs at 4 waves per SIMD
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int wave = tid >> 6, lane = tid & 63;
         __syncthreads();                                   // everyone has read tbox[0]
-        if (ticket && tid == 0) tbox[0] = atomicAdd(ticket, 1);   // next tile, resolved while this one is shaded
+        // next tile: the returning atomic is issued now and its result parked in a register; it reaches the LDS box
+        // at the end of this tile, so thread 0 does not sit on the atomic's latency here
+        int t_next = 0;
+        if (ticket && tid == 0) t_next = atomicAdd(ticket, 1);
         TF_MARK(7);
 
         // ---- tile info
@@ -83,36 +98,35 @@ __global__ __launch_bounds__(256) void shade_forward_kernel(const TfShade S, con
         __syncthreads();
         TF_MARK(0);
 
-        // ---- 1. appearance gather -> V
+        // ---- 1. appearance gather -> V: 8 lanes per sample
         {
-            const int smp = wave * 16 + (lane >> 2), sub = lane & 3;
+            const int smp = wave * 8 + (lane >> 3), sub = lane & 7;
             float u[3] = {ixyz[smp * 3], ixyz[smp * 3 + 1], ixyz[smp * 3 + 2]};
             float* vrow = regA + smp * L.sv;
-            app_products(S, u, sub, vrow);
-            for (int c = S.n_app_total + sub; c < kpad16(S.n_app_total); c += 4) vrow[c] = 0.f;
+            app_products(S, u, sub, vrow, 8);
+            for (int c = S.n_app_total + sub; c < kpad16(S.n_app_total); c += 8) vrow[c] = 0.f;
         }
         __syncthreads();
         TF_MARK(1);
 
-        // ---- 2. basis: feat[s][f] = sum_k B[f][k] V[s][k]; wave w owns sample tile w
-        {
-            f32x4 acc[NB][1];
+        // ---- 2. basis: feat[s][f] = sum_k B[f][k] V[s][k]; (feature tile, sample tile) pairs dealt to the 8 waves
+        for (int pr = wave; pr < 4 * NB; pr += NW) {
+            const int bf = pr >> 2, bs = pr & 3;
+            f32x4 acc[1][1];
+            acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            mma_block<1, 1>(S.basis, kpad16(S.n_app_total), 16 * bf, regA, L.sv, 16 * bs, kpad16(S.n_app_total) / 16, acc, lane);
+            const int smp = 16 * bs + (lane & 15), g = lane >> 4;
 #pragma unroll
-            for (int i = 0; i < NB; ++i) acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            mma_block<NB, 1>(S.basis, kpad16(S.n_app_total), 0, regA, L.sv, wave * 16, kpad16(S.n_app_total) / 16, acc, lane);
-            const int smp = wave * 16 + (lane & 15), g = lane >> 4;
-#pragma unroll
-            for (int i = 0; i < NB; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int f = 16 * i + 4 * g + e;
-                    if (f < S.app_dim) {
-                        regB[smp * L.sx + f] = acc[i][0][e];
-                        if (feat_out && smp < n) feat_out[((size_t)s0 + smp) * S.app_dim + f] = acc[i][0][e];
-                    }
+            for (int e = 0; e < 4; ++e) {
+                const int f = 16 * bf + 4 * g + e;
+                if (f < S.app_dim) {
+                    regB[smp * L.sx + f] = acc[0][0][e];
+                    if (feat_out && smp < n) feat_out[((size_t)s0 + smp) * S.app_dim + f] = acc[0][0][e];
                 }
+            }
         }
         if (feat_out) {      // compute_appfeature hook: features only
+            if (ticket && tid == 0) tbox[0] = t_next;
             __syncthreads();
             continue;
         }
@@ -140,6 +154,7 @@ __global__ __launch_bounds__(256) void shade_forward_kernel(const TfShade S, con
                 }
                 rgb_out[((size_t)s0 + smp) * 3 + ch] = o;
             }
+            if (ticket && tid == 0) tbox[0] = t_next;
             __syncthreads();
             continue;
         }
@@ -151,94 +166,78 @@ __global__ __launch_bounds__(256) void shade_forward_kernel(const TfShade S, con
                 const int src_k = S.pe[b].src, F = S.pe[b].freqs;
                 const int D = src_k == TF_SRC_FEAT ? S.app_dim : 3;
                 const float* mk = S.pe[b].mask;
-                // thread -> (sample, dim) without integer division: dims padded to a power of two
-                const int dp = D <= 4 ? 4 : (D <= 32 ? 32 : 64), dsh = D <= 4 ? 2 : (D <= 32 ? 5 : 6);
-                for (int it = tid; it < M * dp; it += 256) {
-                    const int smp = it >> dsh, d = it & (dp - 1);
-                    if (d >= D) continue;
-                    float* x = regB + smp * L.sx;
-                    const float v = src_k == TF_SRC_FEAT ? x[d] : (src_k == TF_SRC_VIEW ? iview[smp * 3 + d] : ixyz[smp * 3 + d]);
-                    float fr = 1.f;
-                    for (int k = 0; k < F; ++k) {
-                        const float a = v * fr;
-                        float sn, cs;
-                        pe_sincos(a, &sn, &cs);
-                        const int cs_i = d * F + k;
-                        if (mk) {
-                            sn *= mk[cs_i];
-                            cs *= mk[D * F + cs_i];
-                        }
-                        x[off + cs_i] = sn;
-                        x[off + D * F + cs_i] = cs;
-                        fr *= 2.f;
-                    }
-                }
+                float* xb = regB;
+                const int sx = L.sx;
+                pe_block<NT>(regB, L.sx, off, D, F, mk, tid, [&](int smp, int d) {
+                    return src_k == TF_SRC_FEAT ? xb[smp * sx + d] : (src_k == TF_SRC_VIEW ? iview[smp * 3 + d] : ixyz[smp * 3 + d]);
+                });
                 off += 2 * D * F;
             }
             const int kp = kpad16(S.in_c);
-            for (int it = tid; it < M * (kp - S.in_c); it += 256) {
-                const int smp = it / (kp - S.in_c), c = S.in_c + it % (kp - S.in_c);
-                regB[smp * L.sx + c] = 0.f;
+            for (int it = tid; it < M * 16; it += NT) {       // the K padding is < 16 columns
+                const int smp = it >> 4, c = S.in_c + (it & 15);
+                if (c < kp) regB[smp * L.sx + c] = 0.f;
             }
         }
         __syncthreads();
         TF_MARK(3);
 
-        // ---- 4. hidden layers: wave w owns features [16*NF*w, 16*NF*(w+1)) x all 4 sample tiles
+        // ---- 4. hidden layers
         const int FC = S.feature_c;
+        const int f_base = 16 * NFW * (wave % FG), s_base = 16 * NSW * (wave / FG);
         {
-            f32x4 acc[NF][4];
+            f32x4 acc[NFW][NSW];
 #pragma unroll
-            for (int i = 0; i < NF; ++i)
+            for (int i = 0; i < NFW; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            mma_block<NF, 4>(S.w1, kpad16(S.in_c), 16 * NF * wave, regB, L.sx, 0, kpad16(S.in_c) / 16, acc, lane);
+                for (int j = 0; j < NSW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            mma_block<NFW, NSW>(S.w1, kpad16(S.in_c), f_base, regB, L.sx, s_base, kpad16(S.in_c) / 16, acc, lane);
             const int c = lane & 15, g = lane >> 4;
 #pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                const int f = 16 * (NF * wave + i) + 4 * g;
+            for (int i = 0; i < NFW; ++i) {
+                const int f = f_base + 16 * i + 4 * g;
                 const f32x4 bias = *reinterpret_cast<const f32x4*>(S.b1 + f);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NSW; ++j) {
                     f32x4 h = acc[i][j] + bias;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) h[e] = fmaxf(h[e], 0.f);
-                    *reinterpret_cast<f32x4*>(regA + (16 * j + c) * L.sh + f) = h;
+                    *reinterpret_cast<f32x4*>(regA + (s_base + 16 * j + c) * L.sh + f) = h;
                 }
             }
         }
         __syncthreads();
         TF_MARK(4);
         {
-            f32x4 acc[NF][4];
+            f32x4 acc[NFW][NSW];
 #pragma unroll
-            for (int i = 0; i < NF; ++i)
+            for (int i = 0; i < NFW; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            mma_block<NF, 4>(S.w2, kpad16(FC), 16 * NF * wave, regA, L.sh, 0, FC / 16, acc, lane);
+                for (int j = 0; j < NSW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            mma_block<NFW, NSW>(S.w2, kpad16(FC), f_base, regA, L.sh, s_base, FC / 16, acc, lane);
             const int c = lane & 15, g = lane >> 4;
 #pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                const int f = 16 * (NF * wave + i) + 4 * g;
+            for (int i = 0; i < NFW; ++i) {
+                const int f = f_base + 16 * i + 4 * g;
                 const f32x4 bias = *reinterpret_cast<const f32x4*>(S.b2 + f);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NSW; ++j) {
                     f32x4 h = acc[i][j] + bias;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) h[e] = fmaxf(h[e], 0.f);
-                    *reinterpret_cast<f32x4*>(regB + (16 * j + c) * L.sh + f) = h;
+                    *reinterpret_cast<f32x4*>(regB + (s_base + 16 * j + c) * L.sh + f) = h;
                 }
             }
         }
         __syncthreads();
         TF_MARK(5);
 
-        // ---- 5. output layer + sigmoid: 4 lanes per sample
+        // ---- 5. output layer + sigmoid: 8 lanes per sample
         {
-            const int smp = tid >> 2, sub = tid & 3;
+            const int smp = tid >> 3, sub = tid & 7;
             const float* h = regB + smp * L.sh;
             float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-            for (int f = sub * 4; f < FC; f += 16) {
+            for (int f = sub * 4; f < FC; f += 32) {
                 const f32x4 hv = *reinterpret_cast<const f32x4*>(h + f);
                 const f32x4 w0 = *reinterpret_cast<const f32x4*>(S.w3 + f);
                 const f32x4 w1 = *reinterpret_cast<const f32x4*>(S.w3 + FC + f);
@@ -251,6 +250,7 @@ __global__ __launch_bounds__(256) void shade_forward_kernel(const TfShade S, con
                 }
             }
             o0 = quad_sum(o0); o1 = quad_sum(o1); o2 = quad_sum(o2);
+            o0 += __shfl_xor(o0, 4, 64); o1 += __shfl_xor(o1, 4, 64); o2 += __shfl_xor(o2, 4, 64);
             if (sub == 0 && smp < n) {
                 float* o = rgb_out + ((size_t)s0 + smp) * 3;
                 o[0] = 1.f / (1.f + expf(-(o0 + S.b3[0])));
@@ -258,6 +258,7 @@ __global__ __launch_bounds__(256) void shade_forward_kernel(const TfShade S, con
                 o[2] = 1.f / (1.f + expf(-(o2 + S.b3[2])));
             }
         }
+        if (ticket && tid == 0) tbox[0] = t_next;
         __syncthreads();
         TF_MARK(6);
     }
@@ -266,23 +267,23 @@ __global__ __launch_bounds__(256) void shade_forward_kernel(const TfShade S, con
 
 typedef void (*shade_fn_t)(const TfShade, const TileSrc, float*, float*);
 
-template <int NF>
+template <int FT>
 shade_fn_t pick_nb(int nb) {
     switch (nb) {
-        case 1: return shade_forward_kernel<NF, 1>;
-        case 2: return shade_forward_kernel<NF, 2>;
-        case 3: return shade_forward_kernel<NF, 3>;
-        case 4: return shade_forward_kernel<NF, 4>;
+        case 1: return shade_forward_kernel<FT, 1>;
+        case 2: return shade_forward_kernel<FT, 2>;
+        case 3: return shade_forward_kernel<FT, 3>;
+        case 4: return shade_forward_kernel<FT, 4>;
     }
     return nullptr;
 }
 shade_fn_t pick_kernel(const TfShade& S) {
     const int nb = (S.app_dim + 15) / 16;
-    if (S.head != TF_HEAD_MLP) return pick_nb<1>(nb);
+    if (S.head != TF_HEAD_MLP) return pick_nb<4>(nb);
     switch (S.feature_c) {
-        case 64: return pick_nb<1>(nb);
-        case 128: return pick_nb<2>(nb);
-        case 256: return pick_nb<4>(nb);
+        case 64: return pick_nb<4>(nb);
+        case 128: return pick_nb<8>(nb);
+        case 256: return pick_nb<16>(nb);
     }
     return nullptr;
 }
@@ -296,7 +297,7 @@ int launch_shade(const TfShade* S, const TileSrc& src, float* rgb_out, float* fe
     if (bytes > 160 * 1024 - 1024) return (int)hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), bytes, st, *S, src, rgb_out, feat_out);
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(512), bytes, st, *S, src, rgb_out, feat_out);
     return TF_CHECK_LAUNCH();
 }
 

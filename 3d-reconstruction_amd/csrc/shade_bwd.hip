@@ -228,32 +228,15 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                 const int src_k = S.pe[b].src, F = S.pe[b].freqs;
                 const int D = src_k == TF_SRC_FEAT ? S.app_dim : 3;
                 const float* mk = S.pe[b].mask;
-                // thread -> (sample, dim) without integer division: dims padded to a power of two
-                const int dp = D <= 4 ? 4 : (D <= 32 ? 32 : 64), dsh = D <= 4 ? 2 : (D <= 32 ? 5 : 6);
-                for (int it = tid; it < M * dp; it += NT) {
-                    const int smp = it >> dsh, d = it & (dp - 1);
-                    if (d >= D) continue;
-                    float* x = X + smp * L.sx;
-                    const float v = src_k == TF_SRC_FEAT ? x[d] : (src_k == TF_SRC_VIEW ? iview[smp * 3 + d] : ixyz[smp * 3 + d]);
-                    float fr = 1.f;
-                    for (int k = 0; k < F; ++k) {
-                        float sn, cs;
-                        pe_sincos(v * fr, &sn, &cs);
-                        const int ci = d * F + k;
-                        if (mk) {
-                            sn *= mk[ci];
-                            cs *= mk[D * F + ci];
-                        }
-                        x[off + ci] = sn;
-                        x[off + D * F + ci] = cs;
-                        fr *= 2.f;
-                    }
-                }
+                const int sx = L.sx;
+                pe_block<NT>(X, L.sx, off, D, F, mk, tid, [&](int smp, int d) {
+                    return src_k == TF_SRC_FEAT ? X[smp * sx + d] : (src_k == TF_SRC_VIEW ? iview[smp * 3 + d] : ixyz[smp * 3 + d]);
+                });
                 off += 2 * D * F;
             }
-            for (int it = tid; it < M * (kp1 - S.in_c); it += NT) {
-                const int smp = it / (kp1 - S.in_c), c = S.in_c + it % (kp1 - S.in_c);
-                X[smp * L.sx + c] = 0.f;
+            for (int it = tid; it < M * 16; it += NT) {        // the K padding is < 16 columns
+                const int smp = it >> 4, c = S.in_c + (it & 15);
+                if (c < kp1) X[smp * L.sx + c] = 0.f;
             }
         }
         lds_barrier();

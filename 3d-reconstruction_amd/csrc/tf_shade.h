@@ -208,6 +208,92 @@ __device__ __forceinline__ void pe_sincos(float x, float* sn, float* cs) {
     *cs = ((q + 1) & 2) ? -c0 : c0;
 }
 
+// The Cody-Waite + polynomial part of pe_sincos alone (|x| < 8192), branch-free: lets the compiler interleave
+// several independent evaluations (the per-lane range check of pe_sincos splits the code into basic blocks).
+__device__ __forceinline__ void pe_sincos_fast(float x, float* sn, float* cs) {
+    const float n = rintf(x * 0.63661977236758134f);
+    float r = fmaf(-n, 1.5703125f, x);
+    r = fmaf(-n, 4.837512969970703125e-4f, r);
+    r = fmaf(-n, 7.54978995489188e-8f, r);
+    const float r2 = r * r;
+    const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f), r2 * r, r);
+    const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f),
+                          r2 * r2, fmaf(-0.5f, r2, 1.f));
+    const int q = (int)n & 3;
+    const float s0 = (q & 1) ? pc : ps, c0 = (q & 1) ? ps : pc;
+    *sn = (q & 2) ? -s0 : s0;
+    *cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// One positional-encoding block of a 64-sample tile written into X (mlp.py:8-13): for every (sample, dim) the F
+// frequencies v*2^k -> sin at x[off + d*F + k], cos at x[off + D*F + d*F + k], times the optional masks.
+// `val(smp, d)` supplies v.  NT threads cooperate.  The F evaluations of an item are independent and evaluated
+// branch-free two at a time unless some lane of the wave holds a huge argument (wave-uniform test).
+template <int NT, typename ValFn>
+__device__ __forceinline__ void pe_block(float* X, int sx, int off, int D, int F, const float* mk, int tid, ValFn val) {
+    // thread -> (sample, dim) without integer division: dims padded to a power of two
+    const int dp = D <= 4 ? 4 : (D <= 32 ? 32 : 64), dsh = D <= 4 ? 2 : (D <= 32 ? 5 : 6);
+    for (int it = tid; it < M * dp; it += NT) {
+        const int smp = it >> dsh, d = it & (dp - 1);
+        const bool on = d < D;
+        float* x = X + smp * sx;
+        const float v = on ? val(smp, d) : 0.f;
+        const float vmax = ldexpf(fabsf(v), F - 1);
+        if (__builtin_expect(__any(!(vmax < 8192.f)), 0)) {        // rare: some lane needs the full range reduction
+            if (on) {
+                float fr = 1.f;
+                for (int k = 0; k < F; ++k) {
+                    float sn, cs;
+                    pe_sincos(v * fr, &sn, &cs);
+                    const int ci = d * F + k;
+                    if (mk) {
+                        sn *= mk[ci];
+                        cs *= mk[D * F + ci];
+                    }
+                    x[off + ci] = sn;
+                    x[off + D * F + ci] = cs;
+                    fr *= 2.f;
+                }
+            }
+            continue;
+        }
+        float fr = 1.f;
+        int k = 0;
+        for (; k + 1 < F; k += 2) {
+            float s0, c0, s1, c1;
+            pe_sincos_fast(v * fr, &s0, &c0);
+            pe_sincos_fast(v * (fr * 2.f), &s1, &c1);
+            const int ci = d * F + k;
+            if (mk && on) {
+                s0 *= mk[ci];
+                s1 *= mk[ci + 1];
+                c0 *= mk[D * F + ci];
+                c1 *= mk[D * F + ci + 1];
+            }
+            if (on) {
+                x[off + ci] = s0;
+                x[off + ci + 1] = s1;
+                x[off + D * F + ci] = c0;
+                x[off + D * F + ci + 1] = c1;
+            }
+            fr *= 4.f;
+        }
+        if (k < F) {
+            float s0, c0;
+            pe_sincos_fast(v * fr, &s0, &c0);
+            const int ci = d * F + k;
+            if (mk && on) {
+                s0 *= mk[ci];
+                c0 *= mk[D * F + ci];
+            }
+            if (on) {
+                x[off + ci] = s0;
+                x[off + D * F + ci] = c0;
+            }
+        }
+    }
+}
+
 // real SH basis, degree 2 (sh.py:87-112)
 __device__ __forceinline__ void sh9(const float d[3], float y[9]) {
     const float x = d[0], yy_ = d[1], z = d[2];

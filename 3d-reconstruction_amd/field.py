@@ -161,8 +161,7 @@ class _Workspace:
         cap = seg_cap * H.N_SHARDS
         words = (N + 63) // 64
         spec = [("counters", H.N_SHARDS * H.SHARD_STRIDE, torch.int32), ("acc", R, torch.float32),
-                ("depth", R, torch.float32), ("app_offset", R, torch.int32), ("app_count", R, torch.int32),
-                ("val_count", R, torch.int32), ("rgb_map", R * 3, torch.float32),
+                ("app_offset", R, torch.int32), ("app_count", R, torch.int32), ("val_count", R, torch.int32),
                 ("app_ray", cap, torch.int32), ("app_w", cap, torch.float32),
                 ("app_xyz", cap * 3, torch.float32), ("rgb", cap * 3, torch.float32)]
         if save_valid:
@@ -579,7 +578,10 @@ class TensorBase(nn.Module):
         io.rays, io.n_rays, io.n_samples, io.ndc = rays.data_ptr(), R, N, int(bool(ndc_ray))
         io.jitter, io.z_table = H.ptr(jitter), H.ptr(ztab)
         io.save_valid, io.t_stop = int(save_valid), float(self.t_stop)
-        io.acc, io.depth = ws.acc.data_ptr(), ws.depth.data_ptr()
+        # the two per-ray results are written straight into fresh tensors (no copy out of the workspace)
+        out_rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
+        out_depth = torch.empty(R, dtype=torch.float32, device=dev)
+        io.acc, io.depth = ws.acc.data_ptr(), out_depth.data_ptr()
         io.app_offset, io.app_count, io.val_count = ws.app_offset.data_ptr(), ws.app_count.data_ptr(), ws.val_count.data_ptr()
         io.counters = ws.counters.data_ptr()
         io.app_ray, io.app_xyz, io.app_w = ws.app_ray.data_ptr(), ws.app_xyz.data_ptr(), ws.app_w.data_ptr()
@@ -595,8 +597,8 @@ class TensorBase(nn.Module):
                     ws.rgb.data_ptr(), st)
         self._timed("tf_composite_forward", lib.tf_composite_forward, R, ws.app_offset.data_ptr(),
                     ws.app_count.data_ptr(), ws.app_w.data_ptr(), ws.rgb.data_ptr(), ws.acc.data_ptr(), int(use_bg),
-                    ws.rgb_map.data_ptr(), ws.rgb_pre.data_ptr() if save_valid else None, st)
-        ctx = dict(ws=ws, rays=rays, field=field, shade=shade, io=io, keep=(keep, den_masks, app_masks, jitter, ztab),
+                    out_rgb.data_ptr(), ws.rgb_pre.data_ptr() if save_valid else None, st)
+        ctx = dict(ws=ws, rgb_map=out_rgb, depth=out_depth, rays=rays, field=field, shade=shade, io=io, keep=(keep, den_masks, app_masks, jitter, ztab),
                    use_bg=use_bg, ndc=bool(ndc_ray))
         self.last = ctx
         return ctx
@@ -610,10 +612,8 @@ class TensorBase(nn.Module):
         ctx = self._run_forward(rays_chunk, mask, white_bg, is_train, ndc_ray, N_samples, save_valid=False)
         ws = ctx['ws']
         R = ws.R
-        rgb_map = ws.rgb_map.view(R, 3).clone()
-        depth_map = ws.depth.clone()
         num_valid = ws.counters2d[:, 0].sum()
-        return rgb_map, depth_map, num_valid
+        return ctx['rgb_map'], ctx['depth'], num_valid
 
     # ---- public feature hooks (used by compute_alpha in the reference) --------------------------
     def compute_densityfeature(self, xyz_sampled, mask=None):

@@ -65,4 +65,6 @@ def OctreeRender_trilinear_fast(rays, tensorf, mask=None, chunk=4096, N_samples=
     total = LazySampleCount(counts)
     if not getattr(tensorf, 'lazy_sample_count', False):
         total = float(total)
+    if len(rgbs) == 1:      # one chunk (the training call): hand the kernel outputs over without a copy
+        return rgbs[0], None, depth_maps[0], None, None, total
     return torch.cat(rgbs), None, torch.cat(depth_maps), None, None, total
