@@ -13,7 +13,8 @@ import sys
 
 
 def _ours(name):
-    return any(k in name for k in ("march_", "shade_", "composite_kernel", "reduce_replicas", "pack_"))
+    return any(k in name for k in ("march_", "shade_", "composite_kernel", "reduce_replicas", "pack_", "bin_", "adam_kernel",
+                                   "wslab_"))
 
 
 def stats(d, last):
@@ -22,9 +23,11 @@ def stats(d, last):
     for r in csv.DictReader(open(f)):
         per[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     rows = []
+    steps = min((len(v) for k, v in per.items() if "adam_kernel" in k or "shade_backward" in k), default=0)
     for k, v in per.items():
         v.sort()
-        dur = [x[1] for x in (v[-last:] if last and _ours(k) else v)]
+        per_step = max(1, round(len(v) / steps)) if steps else 1      # e.g. the scatter kernels run twice per step
+        dur = [x[1] for x in (v[-last * per_step:] if last and _ours(k) else v)]
         rows.append((sum(dur), k, len(dur), sum(dur) / len(dur), min(dur), max(dur)))
     rows.sort(reverse=True)
     tot = sum(r[0] for r in rows)
