@@ -76,6 +76,7 @@ class TfBinJob(C.Structure):
 
 
 ADAM_MAX_SEG, ADAM_CHUNK = 32, 8192
+BIN_MAX_KEYS = 18000      # TF_BIN_MAX_KEYS: tf_binned_scatter rejects jobs with more keys
 
 
 class TfAdamSeg(C.Structure):
@@ -111,6 +112,7 @@ _SIGS = {
     "tf_march_backward": [C.POINTER(TfField), C.POINTER(TfMarchIO), _fp, _fp, C.c_int, _fp, _fp,
                           C.POINTER(TfFactorGrads), _fp, _fp, _fp],
     "tf_shade_backward_wslab_floats": [C.POINTER(TfShade)],
+    "tf_shade_backward_supported": [C.POINTER(TfShade)],
     "tf_bin_nkeys": [C.POINTER(C.c_int * 3), C.POINTER(C.c_int * 3), C.c_int, C.c_int],
     "tf_bin_keys_per_entry": [C.POINTER(C.c_int * 3)],
     "tf_binned_scatter": [C.POINTER(TfBinJob), _fp],

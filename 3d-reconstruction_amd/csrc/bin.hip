@@ -431,7 +431,7 @@ int tf_bin_keys_per_entry(const int n_comp[3]) {
 int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     const KeyMap K = make_keymap(job->grid, job->factors.n_comp, job->tile, job->bucket);
-    if (K.nkeys != job->nkeys || K.nkeys > 18000) return (int)hipErrorInvalidValue;   // 2 LDS ints per key in K3
+    if (K.nkeys != job->nkeys || K.nkeys > TF_BIN_MAX_KEYS) return (int)hipErrorInvalidValue;   // 2 LDS ints per key in K3
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
     if (!pow2(job->tile) || !pow2(job->bucket) || !pow2(job->chunk)) return (int)hipErrorInvalidValue;
     int csh = 0;

@@ -653,6 +653,13 @@ int tf_debug_phase_cycles_bwd(unsigned long long* out16, int reset) {
 }
 #endif
 
+/* 1 when tf_shade_backward can differentiate this head: MLP heads of width 64 / 128, app_dim <= 32, an input of at
+ * most 192 columns, and a tile (V, X, H1, H2 of 64 samples) that fits the CU's 160 KB of LDS. */
+int tf_shade_backward_supported(const TfShade* shade) {
+    if (!pick_bwd(*shade)) return 0;
+    return (size_t)bwd_lds(*shade).total * sizeof(float) <= 160 * 1024;
+}
+
 /* floats the caller must provide in TfShadeGrads.wslab (256 workgroup slabs) */
 size_t tf_shade_backward_wslab_floats(const TfShade* shade) { return 256 * wslab_floats(*shade); }
 

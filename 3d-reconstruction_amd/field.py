@@ -518,9 +518,18 @@ class TensorBase(nn.Module):
                 binned = (int(lib.tf_bin_nkeys(C.byref(g3), C.byref(cd), self.bin_tile, self.bin_bucket)),
                           int(lib.tf_bin_nkeys(C.byref(g3), C.byref(ca), self.bin_tile, self.bin_bucket)),
                           max(int(lib.tf_bin_keys_per_entry(C.byref(cd))), int(lib.tf_bin_keys_per_entry(C.byref(ca)))))
+                if max(binned[0], binned[1]) > H.BIN_MAX_KEYS:
+                    # grids beyond ~400^3 at 48 components have more (tile, component group) keys than the sort's
+                    # LDS tables hold: those steps take the direct scatter (per-tap atomics, line replicas)
+                    binned = None
             extra = None
             if save_valid:
                 sh, _keep = self._shade_desc([None, None, None], None, dev)
+                if sh.head == H.HEAD_MLP and not H.lib().tf_shade_backward_supported(C.byref(sh)):
+                    raise H.HipError(
+                        f"training is not supported for this shading head: featureC={self.featureC} (64 / 128), "
+                        f"app_dim={self.app_dim} (<= 32), MLP input {sh.in_c} (<= 192), sum(app_n_comp)="
+                        f"{self._n_app_total()} (the 64-sample tile must fit 160 KB of LDS: <= 176 at featureC 128)")
                 wslab = int(H.lib().tf_shade_backward_wslab_floats(C.byref(sh))) if sh.head == H.HEAD_MLP else 64
                 extra = (self._n_app_total(), wslab)
             ws = _Workspace(R, N, dev, save_valid, self._debug_masks, binned, extra)

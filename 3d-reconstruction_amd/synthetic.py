@@ -72,3 +72,53 @@ def bbox_hit_mask(rays, aabb):
     vec = torch.where(d == 0, torch.full_like(d, 1e-6), d)
     ra, rb = (aabb[1] - o) / vec, (aabb[0] - o) / vec
     return torch.maximum(ra, rb).amin(-1) > torch.minimum(ra, rb).amax(-1)
+
+
+# ---- the other BASELINE configurations (C4 forward-facing NDC, C5 Tanks&Temples-like) ----------
+LLFF_AABB = [[-1.5, -1.67, -1.0], [1.5, 1.67, 1.0]]      # dataLoader/llff.py:143
+LLFF_NEAR_FAR = [0.0, 1.0]                                # dataLoader/llff.py:142
+TT_NEAR_FAR = [0.01, 6.0]                                 # dataLoader/tankstemple.py:97
+
+
+def ndc_project(H, W, focal, near, rays_o, rays_d):
+    """Camera-space rays of a forward-facing scene -> NDC rays (the projection dataLoader/ray_utils.py:90-107
+    applies): origins are moved onto the near plane, then x, y are divided by depth and scaled by the image
+    half-extent over the focal length; z maps [near, inf) to [-1, 1)."""
+    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
+    o = rays_o + t[..., None] * rays_d
+    sx, sy = -2.0 * focal / W, -2.0 * focal / H
+    ox, oy, oz = o[..., 0] / o[..., 2], o[..., 1] / o[..., 2], o[..., 2]
+    dx, dy = rays_d[..., 0] / rays_d[..., 2], rays_d[..., 1] / rays_d[..., 2]
+    new_o = torch.stack([sx * ox, sy * oy, 1.0 + 2.0 * near / oz], -1)
+    new_d = torch.stack([sx * (dx - ox), sy * (dy - oy), -2.0 * near / oz], -1)
+    return new_o, new_d
+
+
+def llff_ndc_rays(n_rays, H=756, W=1008, focal=815.0, seed=7):
+    """`n_rays` NDC rays of a forward-facing capture: a 1008x756 pinhole looking down -z (OpenGL convention, as the
+    LLFF poses are) from small random offsets around the origin, projected with ndc_project(near=1)."""
+    g = torch.Generator().manual_seed(seed)
+    px = torch.rand(n_rays, generator=g) * W
+    py = torch.rand(n_rays, generator=g) * H
+    dirs = torch.stack([(px - W / 2) / focal, -(py - H / 2) / focal, -torch.ones(n_rays)], -1)
+    origins = (torch.rand(n_rays, 3, generator=g) - 0.5) * torch.tensor([0.6, 0.4, 0.1])
+    o, d = ndc_project(H, W, focal, 1.0, origins, dirs)
+    return torch.cat([o, d], 1).float()
+
+
+def tt_rays(n_rays, aabb, seed=11):
+    """`n_rays` rays of an inward-facing capture whose cameras stand INSIDE the (enlarged) scene box, as in Tanks&Temples
+    (near = 0.01): origins on a ring at ~60 % of the box half-extent, unit directions towards jittered points near the
+    centre; one in 64 directions has an exactly zero component (the reference's `where(d == 0, 1e-6, d)` branch)."""
+    g = torch.Generator().manual_seed(seed)
+    lo, hi = torch.tensor(aabb[0]), torch.tensor(aabb[1])
+    ctr, half = (lo + hi) / 2, (hi - lo) / 2
+    th = torch.rand(n_rays, generator=g) * 2 * math.pi
+    ring = torch.stack([torch.cos(th), torch.sin(th), 0.3 * (torch.rand(n_rays, generator=g) - 0.5)], -1)
+    o = ctr + 0.6 * half * ring
+    target = ctr + 0.25 * half * (torch.rand(n_rays, 3, generator=g) - 0.5)
+    d = target - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    z = torch.arange(n_rays) % 64 == 0
+    d[z, 2] = 0.0
+    return torch.cat([o, d], 1).float()

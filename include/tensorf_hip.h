@@ -198,6 +198,9 @@ typedef struct TfShadeGrads {
                             * 0: the caller runs tf_binned_scatter on dv_out */
 } TfShadeGrads;
 size_t tf_shade_backward_wslab_floats(const TfShade* shade);
+/* 1 when tf_shade_backward supports this head (MLP, feature_c 64 / 128, app_dim <= 32, in_c <= 192, and the
+ * 64-sample tile of V, X, H1, H2 fits the 160 KB of LDS: sum of appearance components <= 176 at feature_c 128). */
+int tf_shade_backward_supported(const TfShade* shade);
 int tf_shade_backward(const TfShade* shade, const float* rays, int ndc, const int* counters, int seg_cap,
                       const int* app_ray, const float* app_xyz, const float* grad_rgb, const TfShadeGrads* grads,
                       tf_stream_t stream);
@@ -239,6 +242,7 @@ typedef struct TfBinJob {
     int* hist; int* offsets; int* cursor; int* chunk_off; int* binned;
     int nkeys;
 } TfBinJob;
+#define TF_BIN_MAX_KEYS 18000   /* tf_binned_scatter returns hipErrorInvalidValue above this (LDS tables of the sort) */
 /* Decompositions wider than 16 components are split into 16-component groups, each with its own key, so the
  * per-workgroup LDS blocks stay small.  Number of keys for (grid, n_comp, T, LB), and keys emitted per entry: */
 int tf_bin_nkeys(const int grid[3], const int n_comp[3], int tile, int bucket);
