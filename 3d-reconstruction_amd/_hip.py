@@ -76,7 +76,7 @@ class TfBinJob(C.Structure):
 
 
 ADAM_MAX_SEG, ADAM_CHUNK = 32, 8192
-BIN_MAX_KEYS = 18000      # TF_BIN_MAX_KEYS: tf_binned_scatter rejects jobs with more keys
+BIN_MAX_KEYS = 262144     # TF_BIN_MAX_KEYS: tf_binned_scatter rejects jobs with more keys
 
 
 class TfAdamSeg(C.Structure):

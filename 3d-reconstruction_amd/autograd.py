@@ -88,7 +88,7 @@ class _RenderFn(torch.autograd.Function):
             j.grid = c['field'].grid
             j.counters, j.slot, j.seg_cap = ws.counters.data_ptr(), slot, ws.seg_cap
             j.xyz, j.grad, j.grad_ld = xyz.data_ptr(), grad.data_ptr(), grad_ld
-            j.tile, j.bucket, j.chunk = model.bin_tile, model.bin_bucket, model.bin_chunk
+            j.tile, j.bucket, j.chunk = ws.binned_cfg[3], model.bin_bucket, model.bin_chunk
             ints = ws.bin_ints.data_ptr()
             j.hist, j.offsets = ints, ints + 4 * (nmax + 8)
             j.cursor, j.chunk_off = ints + 8 * (nmax + 8), ints + 12 * (nmax + 8)

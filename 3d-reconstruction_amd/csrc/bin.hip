@@ -96,145 +96,161 @@ __global__ __launch_bounds__(256) void zero_ints_kernel(int* __restrict__ p, int
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
 }
 
-// entries of shard g handled by slice k: local = k*256 + tid, += kSlices*256
+constexpr int kKeyRange = 16384;   // keys per LDS pass of the count / scan / fill kernels (64 KB of ints)
+
+// entries of shard g handled by slice k: local = k*256 + tid, += kSlices*256.  Jobs with more than kKeyRange keys
+// (grids beyond ~400^3 at 48 components) are counted in passes over key ranges; the entries of a workgroup are
+// few (cnt / kSlices), so re-deriving their keys per pass is cheap next to the LDS table work.
 __global__ __launch_bounds__(256) void bin_count_kernel(const TfBinJob J, const KeyMap K) {
     extern __shared__ int lh[];
-    for (int i = threadIdx.x; i < K.nkeys; i += 256) lh[i] = 0;
-    __syncthreads();
     const int g = blockIdx.x / kSlices, k = blockIdx.x % kSlices;
     const int cnt = J.counters[g * TF_SHARD_STRIDE + J.slot];
-    for (int local = k * 256 + threadIdx.x; local < cnt; local += kSlices * 256) {
-        const size_t e = (size_t)g * J.seg_cap + local;
-        const float u[3] = {J.xyz[e * 3], J.xyz[e * 3 + 1], J.xyz[e * 3 + 2]};
-        SampleGeom sg;
-        sample_geom(J.grid, u, sg);
-        int keys[6];
-        sample_keys(K, J.grid, sg, keys);
-        TF_FOR_EACH_KEY(K, keys, key, atomicAdd(&lh[key], 1));
+    for (int k0 = 0; k0 < K.nkeys; k0 += kKeyRange) {
+        const int kn = min(kKeyRange, K.nkeys - k0);
+        for (int i = threadIdx.x; i < kn; i += 256) lh[i] = 0;
+        __syncthreads();
+        for (int local = k * 256 + threadIdx.x; local < cnt; local += kSlices * 256) {
+            const size_t e = (size_t)g * J.seg_cap + local;
+            const float u[3] = {J.xyz[e * 3], J.xyz[e * 3 + 1], J.xyz[e * 3 + 2]};
+            SampleGeom sg;
+            sample_geom(J.grid, u, sg);
+            int keys[6];
+            sample_keys(K, J.grid, sg, keys);
+            TF_FOR_EACH_KEY(K, keys, key, if ((unsigned)(key - k0) < (unsigned)kn) atomicAdd(&lh[key - k0], 1));
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < kn; i += 256)
+            if (lh[i]) atomicAdd(&J.hist[k0 + i], lh[i]);
+        __syncthreads();
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < K.nkeys; i += 256)
-        if (lh[i]) atomicAdd(&J.hist[i], lh[i]);
 }
 
 // offsets[] = exclusive prefix of hist[], chunk_off[] = exclusive prefix of ceil(hist/chunk); cursor = offsets.
-// One workgroup (the job has <= 18000 keys): the histogram is pulled into LDS with coalesced loads first — every
-// later pass touches LDS only (per-thread strided global reads made this kernel a chain of memory latencies).
+// One workgroup walks the keys in ranges of kKeyRange with a running carry: the range's histogram is pulled into
+// LDS with coalesced loads first — every later pass touches LDS only (per-thread strided global reads made this
+// kernel a chain of memory latencies).
 __global__ __launch_bounds__(1024) void bin_scan_kernel(const TfBinJob J, int nkeys, int csh /* log2(J.chunk) */) {
-    extern __shared__ int sh[];                 // hist copy [nkeys]
+    extern __shared__ int sh[];                 // hist copy of the current key range
     __shared__ int part[16], part2[16];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < nkeys; i += 1024) sh[i] = J.hist[i];
-    __syncthreads();
-    const int per = (nkeys + 1023) / 1024;
-    const int lo = tid * per, hi = min(nkeys, (tid + 1) * per);
-    int s = 0, s2 = 0;
-    for (int i = lo; i < hi; ++i) {
-        s += sh[i];
-        s2 += (sh[i] + J.chunk - 1) >> csh;
-    }
-    // inclusive scan over the 1024 threads: shuffles inside each wave, then the 16 wave totals
-    int v = s, v2 = s2;
-    const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int a = __shfl_up(v, o, 64), b = __shfl_up(v2, o, 64);
-        if (lane >= o) {
-            v += a;
-            v2 += b;
-        }
-    }
-    if (lane == 63) {
-        part[wv] = v;
-        part2[wv] = v2;
-    }
-    __syncthreads();
-    int wbase = 0, wbase2 = 0, tot = 0, tot2 = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) {
-        const int a = part[w], b = part2[w];
-        if (w < wv) {
-            wbase += a;
-            wbase2 += b;
-        }
-        tot += a;
-        tot2 += b;
-    }
-    v += wbase;
-    v2 += wbase2;
-    // The per-thread key ranges are contiguous, so writing the prefixes straight to global memory would be one
-    // cache line per lane and store; they go to LDS (in place of the histogram) and leave with coalesced stores.
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // item table: work item -> key (chunk index = item - chunk_off[key]); lives behind chunk_off[]
     int* items = J.chunk_off + nkeys + 1;
-    constexpr int kPer = 18;                     // ceil(18000 / 1024): per-thread histogram slice in registers
-    int h[kPer];
+    int carry = 0, carry2 = 0;
+    for (int k0 = 0; k0 < nkeys; k0 += kKeyRange) {
+        const int kn = min(kKeyRange, nkeys - k0);
+        __syncthreads();                        // the previous range's copy-out has finished reading sh / part
+        for (int i = tid; i < kn; i += 1024) sh[i] = J.hist[k0 + i];
+        __syncthreads();
+        constexpr int kPer = kKeyRange / 1024;  // per-thread histogram slice, kept in registers
+        const int lo = tid * kPer, hi = min(kn, (tid + 1) * kPer);
+        int h[kPer], s = 0, s2 = 0;
 #pragma unroll
-    for (int q = 0; q < kPer; ++q) h[q] = lo + q < hi ? sh[lo + q] : 0;
-    int run = v - s, run2 = v2 - s2;
-#pragma unroll
-    for (int q = 0; q < kPer; ++q) {
-        if (lo + q < hi) {
-            sh[lo + q] = run;
-            const int nc = (h[q] + J.chunk - 1) >> csh;
-            for (int c = 0; c < nc; ++c) items[run2 + c] = lo + q;
-            run += h[q];
-            run2 += nc;
+        for (int q = 0; q < kPer; ++q) {
+            h[q] = lo + q < hi ? sh[lo + q] : 0;
+            s += h[q];
+            s2 += (h[q] + J.chunk - 1) >> csh;
         }
-    }
-    __syncthreads();
-    for (int i = tid; i < nkeys; i += 1024) {
-        const int o = sh[i];
-        J.offsets[i] = o;
-        J.cursor[i] = o;
-    }
-    __syncthreads();
-    run2 = v2 - s2;
+        // inclusive scan over the 1024 threads: shuffles inside each wave, then the 16 wave totals
+        int v = s, v2 = s2;
 #pragma unroll
-    for (int q = 0; q < kPer; ++q) {
-        if (lo + q < hi) {
-            sh[lo + q] = run2;
-            run2 += (h[q] + J.chunk - 1) >> csh;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int a = __shfl_up(v, o, 64), b = __shfl_up(v2, o, 64);
+            if (lane >= o) {
+                v += a;
+                v2 += b;
+            }
         }
+        if (lane == 63) {
+            part[wv] = v;
+            part2[wv] = v2;
+        }
+        __syncthreads();
+        int wbase = 0, wbase2 = 0, tot = 0, tot2 = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int a = part[w], b = part2[w];
+            if (w < wv) {
+                wbase += a;
+                wbase2 += b;
+            }
+            tot += a;
+            tot2 += b;
+        }
+        // The per-thread key ranges are contiguous, so writing the prefixes straight to global memory would be one
+        // cache line per lane and store; they go to LDS (in place of the histogram) and leave with coalesced stores.
+        int run = carry + v + wbase - s, run2 = carry2 + v2 + wbase2 - s2;
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            if (lo + q < hi) {
+                sh[lo + q] = run;
+                const int nc = (h[q] + J.chunk - 1) >> csh;
+                for (int c = 0; c < nc; ++c) items[run2 + c] = k0 + lo + q;
+                run += h[q];
+                run2 += nc;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < kn; i += 1024) {
+            const int o = sh[i];
+            J.offsets[k0 + i] = o;
+            J.cursor[k0 + i] = o;
+        }
+        __syncthreads();
+        run2 = carry2 + v2 + wbase2 - s2;
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            if (lo + q < hi) {
+                sh[lo + q] = run2;
+                run2 += (h[q] + J.chunk - 1) >> csh;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < kn; i += 1024) J.chunk_off[k0 + i] = sh[i];
+        carry += tot;
+        carry2 += tot2;
     }
-    __syncthreads();
-    for (int i = tid; i < nkeys; i += 1024) J.chunk_off[i] = sh[i];
     if (tid == 1023) {
-        J.offsets[nkeys] = tot;
-        J.chunk_off[nkeys] = tot2;
+        J.offsets[nkeys] = carry;
+        J.chunk_off[nkeys] = carry2;
     }
 }
 
 __global__ __launch_bounds__(256) void bin_fill_kernel(const TfBinJob J, const KeyMap K) {
     extern __shared__ int lds[];
     int* lh = lds;               // counts, then running ranks
-    int* lb = lds + K.nkeys;     // reserved base per key
-    for (int i = threadIdx.x; i < K.nkeys; i += 256) lh[i] = 0;
-    __syncthreads();
+    int* lb = lds + min(K.nkeys, kKeyRange);   // reserved base per key
     const int g = blockIdx.x / kSlices, k = blockIdx.x % kSlices;
     const int cnt = J.counters[g * TF_SHARD_STRIDE + J.slot];
-    for (int local = k * 256 + threadIdx.x; local < cnt; local += kSlices * 256) {
-        const size_t e = (size_t)g * J.seg_cap + local;
-        const float u[3] = {J.xyz[e * 3], J.xyz[e * 3 + 1], J.xyz[e * 3 + 2]};
-        SampleGeom sg;
-        sample_geom(J.grid, u, sg);
-        int keys[6];
-        sample_keys(K, J.grid, sg, keys);
-        TF_FOR_EACH_KEY(K, keys, key, atomicAdd(&lh[key], 1));
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < K.nkeys; i += 256) {
-        lb[i] = lh[i] ? atomicAdd(&J.cursor[i], lh[i]) : 0;
-        lh[i] = 0;
-    }
-    __syncthreads();
-    for (int local = k * 256 + threadIdx.x; local < cnt; local += kSlices * 256) {
-        const size_t e = (size_t)g * J.seg_cap + local;
-        const float u[3] = {J.xyz[e * 3], J.xyz[e * 3 + 1], J.xyz[e * 3 + 2]};
-        SampleGeom sg;
-        sample_geom(J.grid, u, sg);
-        int keys[6];
-        sample_keys(K, J.grid, sg, keys);
-        TF_FOR_EACH_KEY(K, keys, key, J.binned[lb[key] + atomicAdd(&lh[key], 1)] = (int)e);
+    for (int k0 = 0; k0 < K.nkeys; k0 += kKeyRange) {     // key ranges, as in bin_count_kernel
+        const int kn = min(kKeyRange, K.nkeys - k0);
+        for (int i = threadIdx.x; i < kn; i += 256) lh[i] = 0;
+        __syncthreads();
+        for (int local = k * 256 + threadIdx.x; local < cnt; local += kSlices * 256) {
+            const size_t e = (size_t)g * J.seg_cap + local;
+            const float u[3] = {J.xyz[e * 3], J.xyz[e * 3 + 1], J.xyz[e * 3 + 2]};
+            SampleGeom sg;
+            sample_geom(J.grid, u, sg);
+            int keys[6];
+            sample_keys(K, J.grid, sg, keys);
+            TF_FOR_EACH_KEY(K, keys, key, if ((unsigned)(key - k0) < (unsigned)kn) atomicAdd(&lh[key - k0], 1));
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < kn; i += 256) {
+            lb[i] = lh[i] ? atomicAdd(&J.cursor[k0 + i], lh[i]) : 0;
+            lh[i] = 0;
+        }
+        __syncthreads();
+        for (int local = k * 256 + threadIdx.x; local < cnt; local += kSlices * 256) {
+            const size_t e = (size_t)g * J.seg_cap + local;
+            const float u[3] = {J.xyz[e * 3], J.xyz[e * 3 + 1], J.xyz[e * 3 + 2]};
+            SampleGeom sg;
+            sample_geom(J.grid, u, sg);
+            int keys[6];
+            sample_keys(K, J.grid, sg, keys);
+            TF_FOR_EACH_KEY(K, keys, key,
+                            if ((unsigned)(key - k0) < (unsigned)kn) J.binned[lb[key - k0] + atomicAdd(&lh[key - k0], 1)] = (int)e);
+        }
+        __syncthreads();
     }
 }
 
@@ -431,11 +447,12 @@ int tf_bin_keys_per_entry(const int n_comp[3]) {
 int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     const KeyMap K = make_keymap(job->grid, job->factors.n_comp, job->tile, job->bucket);
-    if (K.nkeys != job->nkeys || K.nkeys > TF_BIN_MAX_KEYS) return (int)hipErrorInvalidValue;   // 2 LDS ints per key in K3
+    if (K.nkeys != job->nkeys || K.nkeys > TF_BIN_MAX_KEYS) return (int)hipErrorInvalidValue;
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
     if (!pow2(job->tile) || !pow2(job->bucket) || !pow2(job->chunk)) return (int)hipErrorInvalidValue;
     int csh = 0;
     while ((1 << csh) < job->chunk) ++csh;
+    const int kr = K.nkeys < kKeyRange ? K.nkeys : kKeyRange;      // keys per LDS pass
     int cmax = job->factors.n_comp[0];
     for (int i = 1; i < 3; ++i) cmax = job->factors.n_comp[i] > cmax ? job->factors.n_comp[i] : cmax;
     cmax = cmax > kCG ? kCG : cmax;
@@ -449,17 +466,17 @@ int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream) {
     hipError_t e = hipSuccess;
     hipLaunchKernelGGL(zero_ints_kernel, dim3((K.nkeys + 255) / 256), dim3(256), 0, st, job->hist, K.nkeys);
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(sizeof(int) * K.nkeys));
+                            (int)(sizeof(int) * kr));
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(bin_count_kernel, dim3(TF_N_SHARDS * kSlices), dim3(256), sizeof(int) * K.nkeys, st, *job, K);
+    hipLaunchKernelGGL(bin_count_kernel, dim3(TF_N_SHARDS * kSlices), dim3(256), sizeof(int) * kr, st, *job, K);
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(sizeof(int) * K.nkeys));
+                            (int)(sizeof(int) * kr));
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), sizeof(int) * K.nkeys, st, *job, K.nkeys, csh);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), sizeof(int) * kr, st, *job, K.nkeys, csh);
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(sizeof(int) * 2 * K.nkeys));
+                            (int)(sizeof(int) * 2 * kr));
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(bin_fill_kernel, dim3(TF_N_SHARDS * kSlices), dim3(256), sizeof(int) * 2 * K.nkeys, st, *job, K);
+    hipLaunchKernelGGL(bin_fill_kernel, dim3(TF_N_SHARDS * kSlices), dim3(256), sizeof(int) * 2 * kr, st, *job, K);
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)sc_bytes);
     if (e != hipSuccess) return (int)e;

@@ -515,12 +515,16 @@ class TensorBase(nn.Module):
                 g3 = (C.c_int * 3)(*self._geom['grid'])
                 cd, ca = (C.c_int * 3)(*self.density_n_comp), (C.c_int * 3)(*self.app_n_comp)
                 lib = H.lib()
-                binned = (int(lib.tf_bin_nkeys(C.byref(g3), C.byref(cd), self.bin_tile, self.bin_bucket)),
-                          int(lib.tf_bin_nkeys(C.byref(g3), C.byref(ca), self.bin_tile, self.bin_bucket)),
-                          max(int(lib.tf_bin_keys_per_entry(C.byref(cd))), int(lib.tf_bin_keys_per_entry(C.byref(ca)))))
-                if max(binned[0], binned[1]) > H.BIN_MAX_KEYS:
-                    # grids beyond ~400^3 at 48 components have more (tile, component group) keys than the sort's
-                    # LDS tables hold: those steps take the direct scatter (per-tap atomics, line replicas)
+                # plane tiles of 8x8 texels, 16x16 on grids whose 8x8 tiling has more (tile, component group) keys
+                # than the sort's LDS tables hold (~400^3 at 48 components); beyond that the direct scatter
+                # (per-tap atomics, line replicas) takes over
+                for tile in (self.bin_tile, 2 * self.bin_tile):
+                    binned = (int(lib.tf_bin_nkeys(C.byref(g3), C.byref(cd), tile, self.bin_bucket)),
+                              int(lib.tf_bin_nkeys(C.byref(g3), C.byref(ca), tile, self.bin_bucket)),
+                              max(int(lib.tf_bin_keys_per_entry(C.byref(cd))), int(lib.tf_bin_keys_per_entry(C.byref(ca)))),
+                              tile)
+                    if max(binned[0], binned[1]) <= H.BIN_MAX_KEYS:
+                        break
                     binned = None
             extra = None
             if save_valid:

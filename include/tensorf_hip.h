@@ -242,7 +242,8 @@ typedef struct TfBinJob {
     int* hist; int* offsets; int* cursor; int* chunk_off; int* binned;
     int nkeys;
 } TfBinJob;
-#define TF_BIN_MAX_KEYS 18000   /* tf_binned_scatter returns hipErrorInvalidValue above this (LDS tables of the sort) */
+#define TF_BIN_MAX_KEYS 262144  /* tf_binned_scatter returns hipErrorInvalidValue above this (the sort walks the keys in
+                                 * LDS-sized ranges of 16384; ~1000^3 grids at 48 components stay below) */
 /* Decompositions wider than 16 components are split into 16-component groups, each with its own key, so the
  * per-workgroup LDS blocks stay small.  Number of keys for (grid, n_comp, T, LB), and keys emitted per entry: */
 int tf_bin_nkeys(const int grid[3], const int n_comp[3], int tile, int bucket);
