@@ -75,6 +75,12 @@ class TfBinJob(C.Structure):
                 ("nkeys", C.c_int)]
 
 
+class TfRegJob(C.Structure):
+    _fields_ = [("density", TfFactors), ("app", TfFactors), ("density_grad", TfFactorGrads), ("app_grad", TfFactorGrads),
+                ("grid", C.c_int * 3), ("w_ortho", C.c_float), ("w_l1", C.c_float), ("w_tv_density", C.c_float),
+                ("w_tv_app", C.c_float), ("loss", _fp), ("scale", _fp), ("want_grad", C.c_int)]
+
+
 ADAM_MAX_SEG, ADAM_CHUNK = 32, 8192
 BIN_MAX_KEYS = 262144     # TF_BIN_MAX_KEYS: tf_binned_scatter rejects jobs with more keys
 
@@ -119,6 +125,7 @@ _SIGS = {
     "tf_shade_backward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp,
                           C.POINTER(TfShadeGrads), _fp],
     "tf_adam_step": [C.POINTER(TfAdamJob), _fp],
+    "tf_regularizers": [C.POINTER(TfRegJob), _fp],
 }
 EXPORTS = tuple(_SIGS) + ("tf_build_info",)
 

@@ -1,0 +1,237 @@
+// reg.hip — the regularisers of the training loop on the VM factor tensors in one pass.
+// Replaces, for TensorVMSplit, the eager terms train.py:340-371 adds to the loss and their autograd:
+//     Ortho_weight * vector_comp_diffs()   tensoRF.py:175-191  mean |off-diagonal of V V^T| per line tensor
+//     L1_weight    * density_L1()          tensoRF.py:193-197  mean |x| of every density plane and line
+//     TV_weight_*  * TV_loss_*(reg)        tensoRF.py:199-205 + loss.py:120-141, 1e-2 * TVLoss per plane:
+//                                          2 (sum (d_h x)^2 / (C (H-1) W) + sum (d_w x)^2 / (C H (W-1)))
+// One kernel walks the six planes (channel-last, 16 B per lane: the four neighbours of a texel are contiguous
+// runs, L2 hits), accumulates the weighted loss and ADDS d loss / d x to the gradient tensors; a second tiny
+// kernel handles the six line tensors (Gram matrix, its sign pattern, and the L1 term).  Eager PyTorch needs
+// ~200 launches and several passes over the 69.5 MB of parameters for the same step (3.7 ms at 300^3).
+#include "tf_device.h"
+
+using namespace tf;
+
+namespace {
+
+struct PlaneDesc {
+    const float* x;   // [H][W][C]
+    float* g;         // same layout, += gradient
+    int H, W, C;
+    float ch, cw;     // weights of sum (d_h x)^2 and sum (d_w x)^2 (TV weight, the 1e-2 and the 2/count folded in)
+    float l1;         // weight of sum |x|  (L1 weight / numel), 0 for the appearance planes
+    int first_row;    // first row of this plane in the launch's flat row space
+};
+struct PlaneJob {
+    PlaneDesc p[6];
+    int n, rows;
+    float* loss;          // loss[0] += weighted total; loss[1] += sum of the TV terms; loss[2] += L1 term (planes part)
+    const float* scale;   // device scalar multiplying the gradients, or NULL (= 1)
+    int want_grad;
+};
+
+// One workgroup per texel row (W * C floats, contiguous): no 64-bit index arithmetic, the row above / below are
+// the same offsets in neighbouring rows.
+__global__ __launch_bounds__(256) void reg_planes_kernel(const PlaneJob J) {
+    const float sc = J.scale ? *J.scale : 1.f;
+    float tv = 0.f, l1 = 0.f;
+    for (int row = blockIdx.x; row < J.rows; row += gridDim.x) {
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < 6; ++q) k += (q < J.n && row >= J.p[q].first_row);
+        const PlaneDesc& P = J.p[k];
+        const int y = row - P.first_row, rowf = P.W * P.C;
+        const float* xr = P.x + (size_t)y * rowf;
+        float* gr = P.g + (size_t)y * rowf;
+        const bool up = y > 0, down = y + 1 < P.H;
+        for (int o = 4 * threadIdx.x; o < rowf; o += 4 * 256) {      // o = x * C + c, whole channel quads
+            const float4_t v = ld4(xr + o);
+            float4_t g = {0.f, 0.f, 0.f, 0.f};
+            if (down) {
+                const float4_t d = v - ld4(xr + o + rowf);
+                g += d * (2.f * P.ch);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tv = fmaf(P.ch * d[e], d[e], tv);      // each forward difference counted once
+            }
+            if (up) g += (v - ld4(xr + o - rowf)) * (2.f * P.ch);
+            if (o + P.C < rowf) {
+                const float4_t d = v - ld4(xr + o + P.C);
+                g += d * (2.f * P.cw);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tv = fmaf(P.cw * d[e], d[e], tv);
+            }
+            if (o >= P.C) g += (v - ld4(xr + o - P.C)) * (2.f * P.cw);
+            if (P.l1 != 0.f) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    l1 = fmaf(P.l1, fabsf(v[e]), l1);
+                    g[e] += v[e] > 0.f ? P.l1 : (v[e] < 0.f ? -P.l1 : 0.f);       // torch.sign: 0 at 0
+                }
+            }
+            if (J.want_grad) {
+                float4_t* gp = reinterpret_cast<float4_t*>(gr + o);
+                *gp = *gp + g * sc;
+            }
+        }
+    }
+    // workgroup reduction of the two partial sums, one atomic triple per workgroup
+    __shared__ float red[2][4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        tv += __shfl_xor(tv, o, 64);
+        l1 += __shfl_xor(l1, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = tv;
+        red[1][threadIdx.x >> 6] = l1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float a = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        const float b = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        if (a != 0.f || b != 0.f) {
+            atomicAdd(J.loss, a + b);
+            atomicAdd(J.loss + 1, a);
+            atomicAdd(J.loss + 2, b);
+        }
+    }
+}
+
+struct LineDesc {
+    const float* v;   // [G][C]  (component c of entry z at z*C + c)
+    float* g;
+    int G, C;
+    float ortho;      // Ortho weight / (C (C-1)), 0 when C == 1
+    float l1;         // L1 weight / numel, 0 for the appearance lines
+    int first_wg;     // first workgroup of this line (one workgroup per component row)
+};
+struct LineJob {
+    LineDesc l[6];
+    float* loss;          // loss[0] += weighted total; loss[2] += L1 (lines part); loss[3] += ortho term
+    const float* scale;
+    int want_grad;
+};
+
+// One workgroup per (line tensor, component a).  Gram row a = V_a . V_b for all b (V = (C, G), C <= 64): threads
+// split the G entries, keep the C partial dot products in registers, and meet in LDS.  The loss is the mean absolute
+// off-diagonal Gram entry; its gradient w.r.t. V_a is (2 / (C (C-1))) * sum_{b != a} sign(Gram_ab) V_b (both (a,b)
+// and (b,a) depend on V_a), evaluated by the same threads on the entries they hold.
+__global__ __launch_bounds__(256) void reg_lines_kernel(const LineJob J) {
+    __shared__ float part[4][64];
+    __shared__ float sgn[64];
+    __shared__ float red[4];
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < 6; ++q) k += ((int)blockIdx.x >= J.l[q].first_wg);
+    const LineDesc& L = J.l[k];
+    const int a = (int)blockIdx.x - L.first_wg, tid = threadIdx.x, C = L.C, G = L.G;
+    const float sc = J.scale ? *J.scale : 1.f;
+    float dot[64];
+#pragma unroll
+    for (int b = 0; b < 64; ++b) dot[b] = 0.f;
+    float l1 = 0.f;
+    if (L.ortho != 0.f) {
+        for (int z = tid; z < G; z += 256) {
+            const float* row = L.v + (size_t)z * C;
+            const float va = row[a];
+#pragma unroll
+            for (int b = 0; b < 64; b += 4) {
+                if (b < C) {
+                    const float4_t r = ld4(row + b);
+                    dot[b] = fmaf(va, r[0], dot[b]); dot[b + 1] = fmaf(va, r[1], dot[b + 1]);
+                    dot[b + 2] = fmaf(va, r[2], dot[b + 2]); dot[b + 3] = fmaf(va, r[3], dot[b + 3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 64; ++b) {
+            float d = dot[b];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+            if ((tid & 63) == 0) part[tid >> 6][b] = d;
+        }
+    }
+    __syncthreads();
+    float ortho = 0.f;
+    if (tid < 64) {
+        float d = 0.f;
+        if (L.ortho != 0.f && tid < C && tid != a) d = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+        sgn[tid] = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        ortho = fabsf(d) * L.ortho;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ortho += __shfl_xor(ortho, o, 64);
+    }
+    __syncthreads();
+    for (int z = tid; z < G; z += 256) {
+        const float* row = L.v + (size_t)z * C;
+        const float x = row[a];
+        float g = 0.f;
+        if (L.ortho != 0.f) {
+            float acc = 0.f;
+            for (int b = 0; b < C; ++b) acc = fmaf(sgn[b], row[b], acc);
+            g = 2.f * L.ortho * acc;
+        }
+        if (L.l1 != 0.f) {
+            l1 = fmaf(L.l1, fabsf(x), l1);
+            g += x > 0.f ? L.l1 : (x < 0.f ? -L.l1 : 0.f);
+        }
+        if (J.want_grad) L.g[(size_t)z * C + a] += g * sc;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) l1 += __shfl_xor(l1, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = l1;
+    __syncthreads();
+    if (tid == 0) {
+        const float b = (red[0] + red[1]) + (red[2] + red[3]);
+        if (ortho != 0.f || b != 0.f) {
+            atomicAdd(J.loss, ortho + b);
+            atomicAdd(J.loss + 2, b);
+            atomicAdd(J.loss + 3, ortho);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int tf_regularizers(const TfRegJob* job, tf_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!job->loss) return (int)hipErrorInvalidValue;
+    PlaneJob pj;
+    LineJob lj;
+    pj.n = 0;
+    pj.rows = 0;
+    int line_wgs = 0;
+    pj.loss = lj.loss = job->loss;
+    pj.scale = lj.scale = job->scale;
+    pj.want_grad = lj.want_grad = job->want_grad;
+    for (int part = 0; part < 2; ++part) {
+        const TfFactors& F = part ? job->app : job->density;
+        const TfFactorGrads& Gd = part ? job->app_grad : job->density_grad;
+        const float tvw = part ? job->w_tv_app : job->w_tv_density;
+        for (int i = 0; i < 3; ++i) {
+            const int W = job->grid[i == 2 ? 1 : 0], H = job->grid[i == 0 ? 1 : 2], Gl = job->grid[2 - i], C = F.n_comp[i];
+            if (!F.plane[i] || !F.line[i] || C < 1 || C > 64 || (C & 3) || H < 2 || W < 2) return (int)hipErrorInvalidValue;
+            if (job->want_grad && (!Gd.plane[i] || !Gd.line[i])) return (int)hipErrorInvalidValue;
+            PlaneDesc& P = pj.p[pj.n++];
+            P.x = F.plane[i];
+            P.g = Gd.plane[i];
+            P.H = H; P.W = W; P.C = C;
+            P.ch = tvw * 1e-2f * 2.f / ((float)C * (H - 1) * W);
+            P.cw = tvw * 1e-2f * 2.f / ((float)C * H * (W - 1));
+            P.l1 = part ? 0.f : job->w_l1 / ((float)C * H * W);
+            P.first_row = pj.rows;
+            pj.rows += H;
+            LineDesc& L = lj.l[part * 3 + i];
+            L.v = F.line[i];
+            L.g = Gd.line[i];
+            L.G = Gl; L.C = C;
+            L.ortho = C > 1 ? job->w_ortho / ((float)C * (C - 1)) : 0.f;
+            L.l1 = part ? 0.f : job->w_l1 / ((float)C * Gl);
+            L.first_wg = line_wgs;
+            line_wgs += C;
+        }
+    }
+    hipLaunchKernelGGL(reg_planes_kernel, dim3((unsigned)(pj.rows < 256 * 8 ? pj.rows : 256 * 8)), dim3(256), 0, st, pj);
+    hipLaunchKernelGGL(reg_lines_kernel, dim3((unsigned)line_wgs), dim3(256), 0, st, lj);
+    return TF_CHECK_LAUNCH();
+}

@@ -18,7 +18,7 @@ import torch
 
 from . import parallel
 from .optim import FusedAdam
-from .regularizers import TVLoss
+from .regularizers import TVLoss, add_regularizer_grads_, fused_supported
 from .renderer import OctreeRender_trilinear_fast
 from .utils import N_to_reso, cal_n_samples, get_free_mask
 
@@ -88,20 +88,32 @@ def train(tensorf, allrays, allrgbs, cfg=None, device="cuda", rank=0, world=1, l
             rays_train, tensorf, mask, chunk=batch, N_samples=nSamples, white_bg=c["white_bg"], ndc_ray=c["ndc_ray"],
             device=device, is_train=True)
         loss = torch.mean((rgb_map - rgb_train) ** 2)
-        total = loss
-        if ortho_w > 0 and hasattr(tensorf, "vector_comp_diffs"):
-            total = total + ortho_w * tensorf.vector_comp_diffs()
-        if l1_w > 0:
-            total = total + l1_w * tensorf.density_L1()
         if tv_d > 0:
             tv_d *= lr_factor
-            total = total + tensorf.TV_loss_density(tvreg) * tv_d
         if tv_a > 0:
             tv_a *= lr_factor
-            total = total + tensorf.TV_loss_app(tvreg) * tv_a
-        opt.zero_grad()
-        total.backward()
-        parallel.allreduce_gradients(tensorf)
+        use_ortho = ortho_w if hasattr(tensorf, "vector_comp_diffs") else 0.0
+        if c.get("fused_regularizers", True) and fused_supported(tensorf):
+            # train.py:340-371 in one pass over the factor tensors (tf_regularizers): the terms do not depend on the
+            # rays, so their gradient is added after the data gradients have been reduced across ranks
+            opt.zero_grad()
+            loss.backward()
+            parallel.allreduce_gradients(tensorf)
+            if max(use_ortho, l1_w, tv_d, tv_a) > 0:
+                add_regularizer_grads_(tensorf, use_ortho, l1_w, max(tv_d, 0.0), max(tv_a, 0.0))
+        else:
+            total = loss
+            if use_ortho > 0:
+                total = total + use_ortho * tensorf.vector_comp_diffs()
+            if l1_w > 0:
+                total = total + l1_w * tensorf.density_L1()
+            if tv_d > 0:
+                total = total + tensorf.TV_loss_density(tvreg) * tv_d
+            if tv_a > 0:
+                total = total + tensorf.TV_loss_app(tvreg) * tv_a
+            opt.zero_grad()
+            total.backward()
+            parallel.allreduce_gradients(tensorf)
         opt.step()
         for g in opt.param_groups:
             g["lr"] = g["lr"] * lr_factor

@@ -21,3 +21,95 @@ class TVLoss(torch.nn.Module):
 
     def forward(self, x):
         return self.TVLoss_weight * total_variation(x)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# One-pass HIP version of the four terms for TensorVMSplit (tf_regularizers, csrc/reg.hip)
+def _reg_job(model, w_ortho, w_l1, w_tv_density, w_tv_app, loss, grads, scale):
+    import ctypes as C
+    from . import _hip as H
+    from .field import is_channel_last
+    job = H.TfRegJob()
+    for part, planes, lines, comps in (("density", model.density_plane, model.density_line, model.density_n_comp),
+                                       ("app", model.app_plane, model.app_line, model.app_n_comp)):
+        fac, fg = getattr(job, part), getattr(job, part + "_grad")
+        for i in range(3):
+            p, l = planes[i], lines[i]
+            if not (p.is_cuda and is_channel_last(p) and is_channel_last(l)):
+                raise H.HipError("fused regularisers need the channel-last CUDA factor tensors of TensorVMSplit")
+            fac.plane[i], fac.line[i], fac.n_comp[i] = p.data_ptr(), l.data_ptr(), int(comps[i])
+            if grads is not None:
+                gp, gl = grads[id(p)], grads[id(l)]
+                if gp.stride() != p.stride() or gl.stride() != l.stride() or gp.dtype != torch.float32:
+                    raise H.HipError("fused regularisers: a gradient is not laid out like its parameter")
+                fg.plane[i], fg.line[i] = gp.data_ptr(), gl.data_ptr()
+        fg.n_rep, fg.rep_stride = 1, 0
+    for k in range(3):
+        job.grid[k] = int(model.gridSize[k])
+    job.w_ortho, job.w_l1, job.w_tv_density, job.w_tv_app = float(w_ortho), float(w_l1), float(w_tv_density), float(w_tv_app)
+    job.loss = loss.data_ptr()
+    job.scale = scale.data_ptr() if scale is not None else None
+    job.want_grad = int(grads is not None)
+    return job
+
+
+def fused_supported(model):
+    """VM decomposition with whole channel quads of at most 64 components per tensor, parameters on the GPU."""
+    comps = list(getattr(model, "density_n_comp", [])) + list(getattr(model, "app_n_comp", []))
+    return (hasattr(model, "density_plane") and len(comps) == 6 and all(c % 4 == 0 and 0 < c <= 64 for c in comps)
+            and model.density_plane[0].is_cuda)
+
+
+def _factor_params(model):
+    return list(model.density_plane) + list(model.density_line) + list(model.app_plane) + list(model.app_line)
+
+
+def _launch(model, weights, grads, scale):
+    import ctypes as C
+    from . import _hip as H
+    from .field import _stream
+    loss = torch.zeros(4, dtype=torch.float32, device=model.density_plane[0].device)
+    job = _reg_job(model, *weights, loss, grads, scale)
+    H.check(H.lib().tf_regularizers(C.byref(job), _stream()), "tf_regularizers")
+    return loss
+
+
+class _FusedRegFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, weights, *params):
+        ctx.model, ctx.weights, ctx.params = model, weights, params
+        return _launch(model, weights, None, None)[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        params = ctx.params
+        total = sum((p.numel() + 63) // 64 * 64 for p in params)
+        flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+        grads, off = {}, 0
+        for p in params:
+            grads[id(p)] = torch.as_strided(flat, p.size(), p.stride(), off)
+            off += (p.numel() + 63) // 64 * 64
+        _launch(ctx.model, ctx.weights, grads, gout.detach().to(torch.float32).contiguous())
+        return (None, None) + tuple(grads[id(p)] for p in params)
+
+
+def fused_regularizers(model, ortho_weight=0.0, l1_weight=0.0, tv_weight_density=0.0, tv_weight_app=0.0):
+    """Differentiable scalar
+        ortho_weight * vector_comp_diffs() + l1_weight * density_L1() + tv_weight_density * TV_loss_density(TVLoss())
+        + tv_weight_app * TV_loss_app(TVLoss())
+    of a TensorVMSplit, computed by two HIP launches (and two more in backward) instead of ~200 eager ones:
+    `total_loss = loss + fused_regularizers(tensorf, ...)` replaces train.py:340-371."""
+    w = (ortho_weight, l1_weight, tv_weight_density, tv_weight_app)
+    return _FusedRegFn.apply(model, w, *_factor_params(model))
+
+
+@torch.no_grad()
+def add_regularizer_grads_(model, ortho_weight=0.0, l1_weight=0.0, tv_weight_density=0.0, tv_weight_app=0.0):
+    """The same sum, with its gradient ADDED to the existing `.grad` of the factor tensors in the same pass (call it
+    between `loss.backward()` and `optimizer.step()`); returns the 4 device floats [total, TV, L1, ortho]."""
+    grads = {}
+    for p in _factor_params(model):
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)      # zeros_like keeps the channel-last strides
+        grads[id(p)] = p.grad
+    return _launch(model, (ortho_weight, l1_weight, tv_weight_density, tv_weight_app), grads, None)

@@ -253,6 +253,23 @@ int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream);
 /* dst[j] = sum_r rep[r*stride + j], j < numel: folds the line-gradient replicas. */
 int tf_reduce_replicas(const float* rep, int n_rep, int stride, int numel, float* dst, tf_stream_t stream);
 
+/* ---- regularisers of the training loop, TensorVMSplit ---------------------------------
+ * loss[0] += w_ortho * vector_comp_diffs() + w_l1 * density_L1() + w_tv_density * TV_loss_density(TVLoss())
+ *            + w_tv_app * TV_loss_app(TVLoss())            (train.py:340-371, tensoRF.py:175-205, loss.py:120-141)
+ * and, with want_grad, the gradient of that sum times *scale (NULL = 1) is ADDED to density_grad / app_grad
+ * (layouts of the factor tensors, n_rep ignored).  loss[1] += TV terms, loss[2] += L1 term, loss[3] += ortho term
+ * (weighted).  `loss` is 4 device floats the caller zeroes.  Requires every n_comp % 4 == 0 and <= 64. */
+typedef struct TfRegJob {
+    TfFactors density, app;
+    TfFactorGrads density_grad, app_grad;
+    int grid[3];
+    float w_ortho, w_l1, w_tv_density, w_tv_app;
+    float* loss;
+    const float* scale;
+    int want_grad;
+} TfRegJob;
+int tf_regularizers(const TfRegJob* job, tf_stream_t stream);
+
 /* ---- optimizer step ---------------------------------------------------------------
  * Replaces `optimizer.step()` of train.py:376 for `torch.optim.Adam(grad_vars, betas=(0.9, 0.99))`
  * (train.py:272-273; eps 1e-8, no weight decay, no amsgrad).  A segment is one parameter tensor walked in

@@ -129,3 +129,44 @@ def test_training_harness_runs_the_intended_schedule(recon):
     assert student.alphaMask is not None and all(torch.isfinite(p).all() for p in student.parameters())
     p = harness.evaluate_psnr(student, rays[:2304], gt[:2304], device=dev)
     assert p > 15.0, p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid,den,app", [([40, 52, 36], [16, 4, 4], [48, 12, 12]), ([64, 64, 64], [16, 16, 16], [48, 48, 48])])
+def test_fused_regularisers_match_the_eager_terms(recon, grid, den, app):
+    """tf_regularizers (one pass) against the torch terms of train.py:340-371, which test_regularisers_match_reference
+    pins to the reference's values: loss, its parts, and the gradient through both entry points."""
+    from recon_amd import synthetic as S
+    dev = "cuda:0"
+    torch.manual_seed(4)
+    aabb = torch.tensor(S.LEGO_AABB, device=dev)
+    model = recon.TensorVMSplit(S.lego_args(density_n_comp=den, app_n_comp=app), aabb, grid, S.LEGO_NEAR_FAR, dev)
+    with torch.no_grad():
+        model.density_plane[1][0, 2, 3, 4] = 0.0           # sign(0) = 0 in the L1 gradient
+    w = dict(ortho_weight=0.01, l1_weight=8e-5, tv_weight_density=0.013, tv_weight_app=0.007)
+    tv = recon.TVLoss()
+    parts = (w["ortho_weight"] * model.vector_comp_diffs(), w["l1_weight"] * model.density_L1(),
+             w["tv_weight_density"] * model.TV_loss_density(tv) + w["tv_weight_app"] * model.TV_loss_app(tv))
+    ref = parts[0] + parts[1] + parts[2]
+    names = [n for n, _ in model.named_parameters() if "_plane." in n or "_line." in n]
+    ref_g = dict(zip(names, torch.autograd.grad(ref, [dict(model.named_parameters())[n] for n in names])))
+    # (1) differentiable entry point, scaled by an upstream factor
+    fused = recon.fused_regularizers(model, **w)
+    assert abs(fused.item() - ref.item()) <= 2e-6 * abs(ref.item())
+    g1 = dict(zip(names, torch.autograd.grad(3.0 * fused, [dict(model.named_parameters())[n] for n in names])))
+    # (2) in-place entry point on top of existing gradients
+    model.zero_grad()
+    for n, p in model.named_parameters():
+        if n in names:
+            p.grad = torch.full_like(p, 0.5)
+    out = recon.add_regularizer_grads_(model, **w)
+    assert abs(out[0].item() - ref.item()) <= 2e-6 * abs(ref.item())
+    assert abs(out[3].item() - parts[0].item()) <= 2e-6 * abs(parts[0].item())
+    assert abs(out[2].item() - parts[1].item()) <= 2e-6 * abs(parts[1].item())
+    assert abs(out[1].item() - parts[2].item()) <= 2e-6 * abs(parts[2].item())
+    for n in names:
+        scale = ref_g[n].abs().max().item()
+        assert (g1[n] / 3.0 - ref_g[n]).abs().max().item() <= 1e-5 * scale, n
+        p = dict(model.named_parameters())[n]
+        assert p.grad.stride() == p.stride()
+        assert (p.grad - 0.5 - ref_g[n]).abs().max().item() <= 1e-5 * scale + 1e-7, n
