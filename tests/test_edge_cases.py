@@ -1,0 +1,88 @@
+"""GPU edge cases of the hot path (empty and ragged batches, rays that miss, the per-ray sample limit, a chunk that
+is not a multiple of the 64 packed-list shards, training on a batch without shaded samples) against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_torch as R
+from tests._golden import Case
+from tests.helpers import build_model, oracle_of
+from tests.test_hip_forward import ATOL_RGB, RTOL
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(recon, name="vm_cubic_eval"):
+    c = Case(name)
+    return c, build_model(recon, c, DEV)
+
+
+@pytest.mark.parametrize("n_rays", [0, 1, 63, 65, 4097])
+def test_ragged_and_empty_batches(recon, n_rays):
+    c, model = _model(recon)
+    rays = c.rays.to(DEV)
+    reps = (n_rays + rays.shape[0] - 1) // max(rays.shape[0], 1) + 1
+    rays = rays.repeat(reps, 1)[:n_rays].contiguous()
+    with torch.no_grad():
+        rgb, depth, nvalid = model(rays, None, white_bg=True, is_train=False)
+    assert rgb.shape == (n_rays, 3) and depth.shape == (n_rays,)
+    if n_rays == 0:
+        assert int(nvalid) == 0
+        out = recon.OctreeRender_trilinear_fast(rays, model, None, chunk=4096, device=DEV)
+        assert out[0].shape[0] == 0 and float(out[5]) == 0.0
+        return
+    cfg, params = oracle_of(model, DEV)
+    with torch.no_grad():
+        o_rgb, o_depth, o_n = R.render_rays(cfg, params, rays, None, white_bg=True, is_train=False)
+    assert int(nvalid) == int(o_n)
+    np.testing.assert_allclose(rgb.cpu().numpy(), o_rgb.cpu().numpy(), rtol=RTOL, atol=ATOL_RGB)
+    np.testing.assert_allclose(depth.cpu().numpy(), o_depth.cpu().numpy(), rtol=RTOL, atol=1e-5)
+
+
+def test_rays_that_miss_the_box_render_background(recon):
+    c, model = _model(recon)
+    o = torch.tensor([[5.0, 5.0, 5.0]], device=DEV).repeat(130, 1)
+    d = torch.nn.functional.normalize(torch.tensor([[1.0, 0.3, 0.2]], device=DEV), dim=-1).repeat(130, 1)
+    rays = torch.cat([o, d], 1)
+    with torch.no_grad():
+        rgb, depth, nvalid = model(rays, None, white_bg=True, is_train=False)
+        cfg, params = oracle_of(model, DEV)
+        o_rgb, o_depth, o_n = R.render_rays(cfg, params, rays, None, white_bg=True, is_train=False)
+    assert int(nvalid) == 0 == int(o_n)
+    assert torch.equal(rgb, torch.ones_like(rgb)) and torch.equal(o_rgb, torch.ones_like(o_rgb))
+    np.testing.assert_allclose(depth.cpu().numpy(), o_depth.cpu().numpy(), rtol=RTOL, atol=1e-6)
+
+
+def test_sample_count_limit(recon):
+    """N_samples up to TF_MAX_SAMPLES (8192) per ray is supported and agrees with the oracle; above it the call fails
+    loudly instead of truncating."""
+    c, model = _model(recon)
+    rays = c.rays.to(DEV)[:96].contiguous()
+    with torch.no_grad():
+        rgb, depth, nvalid = model(rays, None, white_bg=True, is_train=False, N_samples=8192)
+        cfg, params = oracle_of(model, DEV)
+        o_rgb, o_depth, o_n = R.render_rays(cfg, params, rays, None, white_bg=True, is_train=False, n_samples=8192)
+    assert abs(int(nvalid) - int(o_n)) <= 1
+    np.testing.assert_allclose(rgb.cpu().numpy(), o_rgb.cpu().numpy(), rtol=RTOL, atol=ATOL_RGB)
+    with pytest.raises(recon._hip.HipError):
+        model(rays, None, white_bg=True, is_train=False, N_samples=8193)
+
+
+def test_training_step_without_shaded_samples(recon):
+    """A batch whose rays all miss: forward, backward and both optimizers run, every gradient is exactly zero."""
+    c, model = _model(recon, "vm_cubic_train")
+    o = torch.tensor([[5.0, 5.0, 5.0]], device=DEV).repeat(256, 1)
+    d = torch.nn.functional.normalize(torch.tensor([[1.0, 0.3, 0.2]], device=DEV), dim=-1).repeat(256, 1)
+    rays = torch.cat([o, d], 1)
+    opt = recon.FusedAdam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    rgb, _, n = model(rays, None, white_bg=True, is_train=True)
+    loss = torch.mean((rgb - 0.5) ** 2)
+    opt.zero_grad()
+    loss.backward()
+    for k, p in model.named_parameters():
+        assert p.grad is not None and float(p.grad.abs().max()) == 0.0, k
+    opt.step()
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k]), k
