@@ -68,7 +68,7 @@ class TfShadeGrads(C.Structure):
 
 
 class TfBinJob(C.Structure):
-    _fields_ = [("factors", TfFactors), ("grads", TfFactorGrads), ("grid", C.c_int * 3), ("counters", _fp),
+    _fields_ = [("model", C.c_int), ("factors", TfFactors), ("grads", TfFactorGrads), ("grid", C.c_int * 3), ("counters", _fp),
                 ("slot", C.c_int), ("seg_cap", C.c_int), ("xyz", _fp), ("grad", _fp), ("grad_ld", C.c_int),
                 ("tile", C.c_int), ("bucket", C.c_int), ("chunk", C.c_int),
                 ("hist", _fp), ("offsets", _fp), ("cursor", _fp), ("chunk_off", _fp), ("binned", _fp),
@@ -119,8 +119,8 @@ _SIGS = {
                           C.POINTER(TfFactorGrads), _fp, _fp, _fp],
     "tf_shade_backward_wslab_floats": [C.POINTER(TfShade)],
     "tf_shade_backward_supported": [C.POINTER(TfShade)],
-    "tf_bin_nkeys": [C.POINTER(C.c_int * 3), C.POINTER(C.c_int * 3), C.c_int, C.c_int],
-    "tf_bin_keys_per_entry": [C.POINTER(C.c_int * 3)],
+    "tf_bin_nkeys": [C.c_int, C.POINTER(C.c_int * 3), C.POINTER(C.c_int * 3), C.c_int, C.c_int],
+    "tf_bin_keys_per_entry": [C.c_int, C.POINTER(C.c_int * 3)],
     "tf_binned_scatter": [C.POINTER(TfBinJob), _fp],
     "tf_shade_backward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp,
                           C.POINTER(TfShadeGrads), _fp],

@@ -84,6 +84,7 @@ class _RenderFn(torch.autograd.Function):
             nkeys = ws.binned_cfg[0 if part == "density" else 1]
             nmax = max(ws.binned_cfg[0], ws.binned_cfg[1])
             j = H.TfBinJob()
+            j.model = H.MODEL_CP if cp else H.MODEL_VM
             j.factors, j.grads = factors, fgrads
             j.grid = c['field'].grid
             j.counters, j.slot, j.seg_cap = ws.counters.data_ptr(), slot, ws.seg_cap

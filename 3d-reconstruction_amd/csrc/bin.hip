@@ -30,7 +30,8 @@ struct KeyMap {
     int nkeys, keys_per_entry;
 };
 
-__host__ __device__ inline KeyMap make_keymap(const int grid[3], const int n_comp[3], int T, int LB) {
+// cp: TensorCP has line tensors only (all with n_comp[0] components): no plane keys
+__host__ __device__ inline KeyMap make_keymap(const int grid[3], const int n_comp[3], int T, int LB, bool cp = false) {
     KeyMap K;
     K.T = T;
     K.LB = LB;
@@ -40,12 +41,12 @@ __host__ __device__ inline KeyMap make_keymap(const int grid[3], const int n_com
     int run = 0, kpe = 0;
     for (int i = 0; i < 3; ++i) {
         const int W = grid[i == 2 ? 1 : 0], H = grid[i == 0 ? 1 : 2];
-        K.ncg[i] = (n_comp[i] + kCG - 1) / kCG;
+        K.ncg[i] = ((cp ? n_comp[0] : n_comp[i]) + kCG - 1) / kCG;
         K.ntx[i] = (W + T - 1) / T;
-        K.ptiles[i] = K.ntx[i] * ((H + T - 1) / T);
+        K.ptiles[i] = cp ? 0 : K.ntx[i] * ((H + T - 1) / T);
         K.plane_base[i] = run;
         run += K.ptiles[i] * K.ncg[i];
-        kpe += 2 * K.ncg[i];
+        kpe += (cp ? 1 : 2) * K.ncg[i];
     }
     for (int i = 0; i < 3; ++i) {
         K.lbuckets[i] = (grid[2 - i] + LB - 1) / LB;
@@ -84,7 +85,7 @@ __device__ __forceinline__ void sample_keys(const KeyMap& K, const int grid[3], 
 #define TF_FOR_EACH_KEY(K, keys, key, BODY)                                   \
     _Pragma("unroll") for (int _i = 0; _i < 3; ++_i)                          \
         for (int _g = 0; _g < (K).ncg[_i]; ++_g) {                            \
-            { const int key = (keys)[_i] + _g * (K).ptiles[_i]; BODY; }       \
+            if ((K).ptiles[_i]) { const int key = (keys)[_i] + _g * (K).ptiles[_i]; BODY; } \
             { const int key = (keys)[3 + _i] + _g * (K).lbuckets[_i]; BODY; } \
         }
 
@@ -306,11 +307,14 @@ __global__ __launch_bounds__(256, 5) void bin_scatter_kernel(const TfBinJob J, c
             cg = (key - K.plane_base[i]) / K.ptiles[i];
             local = (key - K.plane_base[i]) - cg * K.ptiles[i];
         }
-        const int CF = J.factors.n_comp[i];           // components of the factor tensor (memory stride)
+        const bool cp = J.model == TF_MODEL_CP;
+        const int CF = J.factors.n_comp[cp ? 0 : i];  // components of the factor tensor (memory stride)
         const int c0 = cg * kCG, C = min(kCG, CF - c0); // this key covers components [c0, c0 + C)
-        int coff = c0;
-        for (int q = 0; q < i; ++q) coff += J.factors.n_comp[q];
-        const float* mk = J.factors.mask[i] ? J.factors.mask[i] + c0 : nullptr;
+        int coff = c0;                                  // column of the gradient rows (VM: the axes back to back)
+        for (int q = 0; q < i && !cp; ++q) coff += J.factors.n_comp[q];
+        const float* mk0 = J.factors.mask[cp ? 0 : i];
+        const float* mk = mk0 ? mk0 + c0 : nullptr;
+        const int ja = i == 0 ? 1 : 0, jb = i == 2 ? 1 : 2;     // CP: the other two line tensors
         const int T1 = K.T + 1;
         const int nblk = is_line ? (K.LB + 1) * C : T1 * T1 * C;
         for (int q = tid; q < 4 * nblk; q += 256) blk0[q] = 0.f;
@@ -356,19 +360,31 @@ __global__ __launch_bounds__(256, 5) void bin_scatter_kernel(const TfBinJob J, c
                 float* dst = pre + ent * C;
                 if (vec) {
                     for (int c = 4 * sub; c < C; c += 4 * LPE) {
-                        float4_t v = is_line ? bilerp4(J.factors.plane[i], CF, tp, c0 + c) : lerp4(J.factors.line[i], CF, tl, c0 + c);
+                        float4_t v;
+                        if (cp) {     // d(L0 L1 L2 m)/dL_i = the other two lines' values (tensoRF.py:363-384)
+                            v = lerp4(J.factors.line[ja], CF, make_tap1(u[vecm(ja)], J.grid[vecm(ja)]), c0 + c) *
+                                lerp4(J.factors.line[jb], CF, make_tap1(u[vecm(jb)], J.grid[vecm(jb)]), c0 + c);
+                        } else {
+                            v = is_line ? bilerp4(J.factors.plane[i], CF, tp, c0 + c) : lerp4(J.factors.line[i], CF, tl, c0 + c);
+                        }
                         v *= grow ? ld4(grow + c) : (float4_t){df, df, df, df};
                         if (mk) {
                             const float4_t m = ld4(mk + c);
-                            v *= m * m;
+                            v *= cp ? m : m * m;      // VM: each factor carries the mask; CP: the product does, once
                         }
                         *reinterpret_cast<float4_t*>(dst + c) = v;
                     }
                 } else {
                     for (int c = sub; c < C; c += LPE) {
-                        float v = is_line ? bilerp1(J.factors.plane[i], CF, tp, c0 + c) : lerp1(J.factors.line[i], CF, tl, c0 + c);
+                        float v;
+                        if (cp) {
+                            v = lerp1(J.factors.line[ja], CF, make_tap1(u[vecm(ja)], J.grid[vecm(ja)]), c0 + c) *
+                                lerp1(J.factors.line[jb], CF, make_tap1(u[vecm(jb)], J.grid[vecm(jb)]), c0 + c);
+                        } else {
+                            v = is_line ? bilerp1(J.factors.plane[i], CF, tp, c0 + c) : lerp1(J.factors.line[i], CF, tl, c0 + c);
+                        }
                         v *= grow ? grow[c] : df;
-                        if (mk) v *= mk[c] * mk[c];
+                        if (mk) v *= cp ? mk[c] : mk[c] * mk[c];
                         dst[c] = v;
                     }
                 }
@@ -435,18 +451,17 @@ int tf_debug_phase_cycles_bin(unsigned long long* out16, int reset) {
 }
 #endif
 
-int tf_bin_nkeys(const int grid[3], const int n_comp[3], int tile, int bucket) {
-    return make_keymap(grid, n_comp, tile, bucket).nkeys;
+int tf_bin_nkeys(int model, const int grid[3], const int n_comp[3], int tile, int bucket) {
+    return make_keymap(grid, n_comp, tile, bucket, model == TF_MODEL_CP).nkeys;
 }
-int tf_bin_keys_per_entry(const int n_comp[3]) {
-    int k = 0;
-    for (int i = 0; i < 3; ++i) k += 2 * ((n_comp[i] + kCG - 1) / kCG);
-    return k;
+int tf_bin_keys_per_entry(int model, const int n_comp[3]) {
+    const int grid1[3] = {8, 8, 8};
+    return make_keymap(grid1, n_comp, 8, 8, model == TF_MODEL_CP).keys_per_entry;
 }
 
 int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
-    const KeyMap K = make_keymap(job->grid, job->factors.n_comp, job->tile, job->bucket);
+    const KeyMap K = make_keymap(job->grid, job->factors.n_comp, job->tile, job->bucket, job->model == TF_MODEL_CP);
     if (K.nkeys != job->nkeys || K.nkeys > TF_BIN_MAX_KEYS) return (int)hipErrorInvalidValue;
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
     if (!pow2(job->tile) || !pow2(job->bucket) || !pow2(job->chunk)) return (int)hipErrorInvalidValue;
@@ -454,7 +469,7 @@ int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream) {
     while ((1 << csh) < job->chunk) ++csh;
     const int kr = K.nkeys < kKeyRange ? K.nkeys : kKeyRange;      // keys per LDS pass
     int cmax = job->factors.n_comp[0];
-    for (int i = 1; i < 3; ++i) cmax = job->factors.n_comp[i] > cmax ? job->factors.n_comp[i] : cmax;
+    for (int i = 1; i < 3 && job->model != TF_MODEL_CP; ++i) cmax = job->factors.n_comp[i] > cmax ? job->factors.n_comp[i] : cmax;
     cmax = cmax > kCG ? kCG : cmax;
     const size_t blk_bytes = (size_t)(job->tile + 1) * (job->tile + 1) * cmax * 4;
     const size_t lblk_bytes = (size_t)(job->bucket + 1) * cmax * 4;

@@ -244,7 +244,6 @@ int tf_march_backward(const TfField* field, const TfMarchIO* io, const float* gr
     const int ctot = field->density.n_comp[0] + field->density.n_comp[1] + field->density.n_comp[2];
     const size_t lds = (size_t)ncap * 12 + (field->model == TF_MODEL_VM ? (size_t)chunk_lds_words(ctot) * 4 : 0);
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
-    if (field->model != TF_MODEL_VM) ent_xyz = ent_df = nullptr;
     BwdArgs B{grad_rgb_map, rgb_pre, rgb, grad_rgb, white_bg, ent_xyz, ent_df};
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(march_backward_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -511,17 +511,20 @@ class TensorBase(nn.Module):
         ws = self._ws_cache.get(key)
         if ws is None or save_valid:
             binned = None
-            if save_valid and not self._is_cp() and self.binned_scatter:
+            if save_valid and self.binned_scatter:
                 g3 = (C.c_int * 3)(*self._geom['grid'])
-                cd, ca = (C.c_int * 3)(*self.density_n_comp), (C.c_int * 3)(*self.app_n_comp)
+                mdl = H.MODEL_CP if self._is_cp() else H.MODEL_VM
+                cd = (C.c_int * 3)(*([self.density_n_comp[0]] * 3 if self._is_cp() else self.density_n_comp))
+                ca = (C.c_int * 3)(*([self.app_n_comp[0]] * 3 if self._is_cp() else self.app_n_comp))
                 lib = H.lib()
                 # plane tiles of 8x8 texels, 16x16 on grids whose 8x8 tiling has more (tile, component group) keys
                 # than the sort's LDS tables hold (~400^3 at 48 components); beyond that the direct scatter
                 # (per-tap atomics, line replicas) takes over
                 for tile in (self.bin_tile, 2 * self.bin_tile):
-                    binned = (int(lib.tf_bin_nkeys(C.byref(g3), C.byref(cd), tile, self.bin_bucket)),
-                              int(lib.tf_bin_nkeys(C.byref(g3), C.byref(ca), tile, self.bin_bucket)),
-                              max(int(lib.tf_bin_keys_per_entry(C.byref(cd))), int(lib.tf_bin_keys_per_entry(C.byref(ca)))),
+                    binned = (int(lib.tf_bin_nkeys(mdl, C.byref(g3), C.byref(cd), tile, self.bin_bucket)),
+                              int(lib.tf_bin_nkeys(mdl, C.byref(g3), C.byref(ca), tile, self.bin_bucket)),
+                              max(int(lib.tf_bin_keys_per_entry(mdl, C.byref(cd))),
+                                  int(lib.tf_bin_keys_per_entry(mdl, C.byref(ca)))),
                               tile)
                     if max(binned[0], binned[1]) <= H.BIN_MAX_KEYS:
                         break

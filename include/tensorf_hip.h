@@ -182,7 +182,7 @@ int tf_appfeature_points(const TfShade* shade, const float* xyz_n, int n, float*
 int tf_march_backward(const TfField* field, const TfMarchIO* io, const float* grad_rgb_map, const float* rgb_pre,
                       int white_bg, const float* rgb, float* grad_rgb, const TfFactorGrads* dgrads,
                       float* ent_xyz, float* ent_df, tf_stream_t stream);
-/* ent_xyz/ent_df != NULL (VM): instead of scattering, the kernel appends one entry (normalised xyz, dL/df) per
+/* ent_xyz/ent_df != NULL: instead of scattering, the kernel appends one entry (normalised xyz, dL/df) per
  * density sample with a non-zero gradient to the sharded entry list (counter slot 3) for tf_binned_scatter. */
 
 /* Backward of the shading head + appearance lookup: recomputes the tile forward, then accumulates
@@ -227,7 +227,9 @@ int tf_filter_rays(const TfField* field, const float* rays, int n_rays, int bbox
  * contiguous atomics.  Entries live in the sharded layout of the packed app list:
  * shard g = [g*seg_cap, g*seg_cap + counters[g*TF_SHARD_STRIDE + slot]). */
 typedef struct TfBinJob {
-    TfFactors factors;        /* the field being differentiated (density or appearance), VM only */
+    int model;                /* TF_MODEL_VM, or TF_MODEL_CP (line keys only; a line's gradient is dL/d(product) times
+                               * the other two lines' values; `grad` rows hold factors.n_comp[0] columns) */
+    TfFactors factors;        /* the field being differentiated (density or appearance) */
     TfFactorGrads grads;
     int grid[3];
     const int* counters;      /* sharded entry counters */
@@ -246,8 +248,8 @@ typedef struct TfBinJob {
                                  * LDS-sized ranges of 16384; ~1000^3 grids at 48 components stay below) */
 /* Decompositions wider than 16 components are split into 16-component groups, each with its own key, so the
  * per-workgroup LDS blocks stay small.  Number of keys for (grid, n_comp, T, LB), and keys emitted per entry: */
-int tf_bin_nkeys(const int grid[3], const int n_comp[3], int tile, int bucket);
-int tf_bin_keys_per_entry(const int n_comp[3]);
+int tf_bin_nkeys(int model, const int grid[3], const int n_comp[3], int tile, int bucket);
+int tf_bin_keys_per_entry(int model, const int n_comp[3]);
 int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream);
 
 /* dst[j] = sum_r rep[r*stride + j], j < numel: folds the line-gradient replicas. */
