@@ -11,6 +11,7 @@ with the undefined names bound to their config keys).
 
 Host-side Python on the product API only (no oracle).  Data-parallel runs pass `rank` / `world` and get the
 gradient all-reduce of parallel.py."""
+import gc
 import math
 
 import numpy as np
@@ -76,6 +77,10 @@ def train(tensorf, allrays, allrgbs, cfg=None, device="cuda", rank=0, world=1, l
         allrays, allrgbs = tensorf.filtering_rays(allrays, allrgbs, bbox_only=True)      # train.py:291
     sampler = SimpleSampler(allrays.shape[0], batch * world, seed)
     hist = dict(loss=[], psnr=[], events=[], n_samples=[])
+    # park the objects that exist now in the collector's permanent generation: at ~1 ms per step a full cyclic
+    # collection over the set-up's long-lived objects (a few ms) would otherwise recur every handful of steps
+    gc.collect()
+    gc.freeze()
     for it in range(n_iters):
         ids = parallel.shard_ids(sampler.nextids(), rank, world).to(allrays.device)
         rays_train, rgb_train = allrays[ids], allrgbs[ids].to(device)
@@ -142,6 +147,7 @@ def train(tensorf, allrays, allrgbs, cfg=None, device="cuda", rank=0, world=1, l
             opt = make_opt(c["lr_init"] * scale, c["lr_basis"] * scale)
             hist["events"].append((it, "upsample", reso_cur, nSamples))
         hist["n_samples"].append(nSamples)
+    gc.unfreeze()
     return hist
 
 

@@ -224,6 +224,11 @@ def main():
         return graphed.step(rays[ids], targets[ids])
 
     step = (graph_step if use_graph else train_step) if args.mode == "train" else eval_step
+    # the scene set-up leaves ~10^6 long-lived Python objects behind; without this the cyclic collector re-walks
+    # them every few steps of the eager paths (measured: 3 ms pauses on a 0.2 ms step)
+    import gc
+    gc.collect()
+    gc.freeze()
     torch.manual_seed(1234 + rank)
     for i in range(args.warmup):
         step(i)

@@ -7,9 +7,11 @@ import recon_amd as recon
 from tests.test_full_size import _scene
 
 DEV = "cuda:0"
+import gc
 for name in sys.argv[1:] or ["C1_vm128", "C2_vm300", "C3_cp300_sh", "C3_cp300_mlp", "C4_ndc", "C5_tt640"]:
     model, rays, N, ndc, white = _scene(recon, name)
     model.lazy_sample_count = True
+    gc.collect(); gc.freeze()
     target = torch.rand(rays.shape[0], 3, device=DEV)
     def ev():
         with torch.no_grad():
@@ -18,7 +20,9 @@ for name in sys.argv[1:] or ["C1_vm128", "C2_vm300", "C3_cp300_sh", "C3_cp300_ml
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(30): ev()
     torch.cuda.synchronize(); t_eval = (time.perf_counter() - t0) / 30
-    line = f"{name:14s} grid {model.gridSize.tolist()} N={N}: eval {t_eval*1e3:.3f} ms = {4096/t_eval/1e6:.2f} M rays/s"
+    cs = model.last["ws"].counters2d[:, :3].sum(0).tolist()
+    line = (f"{name:14s} grid {model.gridSize.tolist()} N={N} per ray: {cs[2]/4096:.0f} in-bbox {cs[1]/4096:.1f} density "
+            f"{cs[0]/4096:.1f} shaded: eval {t_eval*1e3:.3f} ms = {4096/t_eval/1e6:.2f} M rays/s")
     if model.shadingMode not in ("SH", "RGB"):
         opt = recon.FusedAdam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
         def tr():
