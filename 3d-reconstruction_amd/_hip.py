@@ -72,7 +72,19 @@ class TfBinJob(C.Structure):
                 ("slot", C.c_int), ("seg_cap", C.c_int), ("xyz", _fp), ("grad", _fp), ("grad_ld", C.c_int),
                 ("tile", C.c_int), ("bucket", C.c_int), ("chunk", C.c_int),
                 ("hist", _fp), ("offsets", _fp), ("cursor", _fp), ("chunk_off", _fp), ("binned", _fp),
-                ("nkeys", C.c_int)]
+                ("nkeys", C.c_int), ("hist_zeroed", C.c_int)]
+
+
+PACK_MAX = 8
+
+
+class TfPackItem(C.Structure):
+    _fields_ = [("src", _fp), ("dst", _fp), ("rows", C.c_int), ("cols", C.c_int), ("rows_pad", C.c_int),
+                ("transpose", C.c_int)]
+
+
+class TfPackJob(C.Structure):
+    _fields_ = [("n", C.c_int), ("pad_", C.c_int), ("item", TfPackItem * PACK_MAX)]
 
 
 class TfRegJob(C.Structure):
@@ -92,7 +104,7 @@ class TfAdamSeg(C.Structure):
 class TfAdamJob(C.Structure):
     _fields_ = [("n_seg", C.c_int), ("pad_", C.c_int), ("seg", TfAdamSeg * ADAM_MAX_SEG),
                 ("chunk_end", C.c_int * ADAM_MAX_SEG), ("lrs", _fp), ("step", _fp),
-                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double)]
+                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("step_rw", _fp), ("arrivals", _fp)]
 
 
 class HipError(RuntimeError):
@@ -105,6 +117,8 @@ _SIGS = {
     "tf_pack_alpha_cells": [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp],
     "tf_pack_matrix": [_fp, C.c_int, C.c_int, _fp, C.c_int, _fp],
     "tf_pack_matrix_t": [_fp, C.c_int, C.c_int, _fp, C.c_int, _fp],
+    "tf_pack_matrices": [C.POINTER(TfPackJob), _fp],
+    "tf_mse_grad": [_fp, _fp, C.c_int, _fp, _fp, _fp],
     "tf_march_forward": [C.POINTER(TfField), C.POINTER(TfMarchIO), _fp],
     "tf_shade_forward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp],
     "tf_composite_forward": [C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp],

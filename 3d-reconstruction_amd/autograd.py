@@ -44,13 +44,16 @@ def _grad_buffers(named, n_rep=N_REP):
 class _RenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, rays, mask, white_bg, is_train, ndc_ray, N_samples, names, *params):
+        ctx.set_materialize_grads(False)     # no zero-filled gradients for the two non-differentiable results
         c = model._run_forward(rays, mask, white_bg, is_train, ndc_ray, N_samples, save_valid=True)
         ws = c['ws']
         ctx.model, ctx.c, ctx.names = model, c, names
         ctx.versions = [p._version for p in params]
         ctx.params = params
         rgb_map, depth = c.pop('rgb_map'), c.pop('depth')     # fresh tensors written by the kernels
-        nvalid = ws.counters2d[:, 0].sum()
+        # the third result (`app_mask.sum()`, tensorBase.py:390) costs a reduction launch; callers that drop it
+        # (graph.GraphedTrainStep) switch it off and get the un-summed per-shard counters' first entry instead
+        nvalid = ws.counters2d[:, 0].sum() if model.count_samples else ws.counters2d[0, 0]
         ctx.mark_non_differentiable(depth, nvalid)
         return rgb_map, depth, nvalid
 
@@ -68,6 +71,8 @@ class _RenderFn(torch.autograd.Function):
         n_rep = 0 if binned else N_REP
         grads, flat, offs, grad_len, line_len = _grad_buffers(named, n_rep)
         model.grad_flat = flat[:grad_len]   # every gradient of this step, one contiguous buffer (parallel.py)
+        if g_rgb is None:
+            g_rgb = torch.zeros(ws.R, 3, dtype=torch.float32, device=ctx.params[0].device)
         g = g_rgb.detach().to(torch.float32).contiguous()
         cp = model._is_cp()
         rep0 = flat.data_ptr() + 4 * (grad_len if n_rep else 0)   # replica 0 of the line block (binned: the head itself)
@@ -91,8 +96,10 @@ class _RenderFn(torch.autograd.Function):
             j.xyz, j.grad, j.grad_ld = xyz.data_ptr(), grad.data_ptr(), grad_ld
             j.tile, j.bucket, j.chunk = ws.binned_cfg[3], model.bin_bucket, model.bin_chunk
             ints = ws.bin_ints.data_ptr()
-            j.hist, j.offsets = ints, ints + 4 * (nmax + 8)
-            j.cursor, j.chunk_off = ints + 8 * (nmax + 8), ints + 12 * (nmax + 8)
+            j.hist = (ws.hist_density if part == "density" else ws.hist_app).data_ptr()
+            j.hist_zeroed = 1                     # zeroed with the shard counters at the start of the forward
+            j.offsets = ints
+            j.cursor, j.chunk_off = ints + 4 * (nmax + 8), ints + 8 * (nmax + 8)
             j.binned, j.nkeys = ws.binned.data_ptr(), nkeys
             model._timed("tf_binned_scatter_" + part, lib.tf_binned_scatter, C.byref(j), st)
 

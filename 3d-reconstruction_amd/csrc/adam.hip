@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const TfAdamJob J) {
         int s = 0;
         while (s + 1 < J.n_seg && (int)blockIdx.x >= J.chunk_end[s]) ++s;
         s_seg = s;
-        const double t = (double)*J.step;
+        const double t = (double)*J.step + 1.0;      // *step counts the completed updates; this one is number t
         const double bc1 = 1.0 - pow(J.beta1, t), bc2 = 1.0 - pow(J.beta2, t);
         s_hyp[0] = (float)((double)J.lrs[J.seg[s].group] / (double)(float)bc1);   // step size
         s_hyp[1] = (float)sqrt(bc2);
@@ -58,6 +58,18 @@ __global__ __launch_bounds__(256) void adam_kernel(const TfAdamJob J) {
         *reinterpret_cast<tf::float4_t*>(v + 4 * i) = vv;
     }
     for (long long i = 4 * n4 + tid; i < n; i += 256) upd(p[i], g[i], m[i], v[i]);
+    // every workgroup has read *step by now or will have before it arrives here: the last one to arrive advances the
+    // count for the next launch and re-arms the arrival counter (no separate "step += 1" launch per update)
+    if (J.arrivals) {
+        __syncthreads();
+        if (tid == 0) {     // (thread 0 consumed *step before the first barrier of this workgroup: no fence needed,
+                            //  and a device-scope fence here would write back the L2 once per workgroup)
+            if (atomicAdd(J.arrivals, 1u) == gridDim.x - 1) {
+                *J.step_rw = *J.step + 1.f;
+                *J.arrivals = 0u;
+            }
+        }
+    }
 }
 
 }  // namespace

@@ -479,7 +479,8 @@ int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream) {
     int per_cu = (int)((160 * 1024) / (sc_bytes + 512));
     per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
     hipError_t e = hipSuccess;
-    hipLaunchKernelGGL(zero_ints_kernel, dim3((K.nkeys + 255) / 256), dim3(256), 0, st, job->hist, K.nkeys);
+    if (!job->hist_zeroed)
+        hipLaunchKernelGGL(zero_ints_kernel, dim3((K.nkeys + 255) / 256), dim3(256), 0, st, job->hist, K.nkeys);
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(sizeof(int) * kr));
     if (e != hipSuccess) return (int)e;

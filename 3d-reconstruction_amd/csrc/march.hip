@@ -237,6 +237,46 @@ __global__ __launch_bounds__(256) void pack_matrix_t_kernel(const float* __restr
     }
 }
 
+// several pack jobs in one launch (blockIdx.y = job): the training step refreshes 5 padded / transposed weight
+// copies after every optimizer step
+__global__ __launch_bounds__(256) void pack_matrices_kernel(const TfPackJob J) {
+    const TfPackItem& P = J.item[blockIdx.y];
+    const int kp = (P.cols + 15) & ~15, total = P.rows_pad * kp;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int r, c;
+        if (P.transpose) {
+            c = i / P.rows_pad;
+            r = i - c * P.rows_pad;
+        } else {
+            r = i / kp;
+            c = i - r * kp;
+        }
+        P.dst[i] = (r < P.rows && c < P.cols) ? P.src[(size_t)r * P.cols + c] : 0.f;
+    }
+}
+
+// loss = mean((a - b)^2) over n floats and grad = d loss / d a = 2 (a - b) / n, one workgroup (n is 3 x rays)
+__global__ __launch_bounds__(1024) void mse_grad_kernel(const float* __restrict__ a, const float* __restrict__ b, int n,
+                                                        float* __restrict__ loss, float* __restrict__ grad) {
+    __shared__ float red[16];
+    const float inv = 1.f / (float)n;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float d = a[i] - b[i];
+        s = fmaf(d, d, s);
+        grad[i] = 2.f * d * inv;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        *loss = t * inv;
+    }
+}
+
 // rgb_map = sum_k w_k rgb_k (+ 1 - acc) clamped  (tensorBase.py:378-384).  8 lanes per ray; a ray's entries
 // are contiguous and in sample order, so the summation order is fixed (deterministic).
 __global__ __launch_bounds__(256) void composite_kernel(int n_rays, const int* __restrict__ app_offset,
@@ -296,6 +336,23 @@ int tf_pack_matrix_t(const float* src, int rows, int cols, float* dst, int rows_
     const int total = kp * rows_pad;
     hipLaunchKernelGGL(pack_matrix_t_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, rows,
                        cols, dst, rows_pad, kp);
+    return TF_CHECK_LAUNCH();
+}
+
+int tf_pack_matrices(const TfPackJob* job, tf_stream_t stream) {
+    if (job->n < 1 || job->n > TF_PACK_MAX) return (int)hipErrorInvalidValue;
+    int most = 0;
+    for (int k = 0; k < job->n; ++k) {
+        const int total = job->item[k].rows_pad * ((job->item[k].cols + 15) & ~15);
+        most = total > most ? total : most;
+    }
+    hipLaunchKernelGGL(pack_matrices_kernel, dim3((most + 255) / 256, job->n), dim3(256), 0, (hipStream_t)stream, *job);
+    return TF_CHECK_LAUNCH();
+}
+
+int tf_mse_grad(const float* a, const float* b, int n, float* loss, float* grad, tf_stream_t stream) {
+    if (n <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(mse_grad_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, b, n, loss, grad);
     return TF_CHECK_LAUNCH();
 }
 

@@ -160,7 +160,11 @@ class _Workspace:
         seg_cap = ((R + H.N_SHARDS - 1) // H.N_SHARDS) * N
         cap = seg_cap * H.N_SHARDS
         words = (N + 63) // 64
-        spec = [("counters", H.N_SHARDS * H.SHARD_STRIDE, torch.int32), ("acc", R, torch.float32),
+        n_ctr = H.N_SHARDS * H.SHARD_STRIDE
+        # everything that must be zero when a forward starts sits in ONE block (one fill launch per step): the shard
+        # counters and, in training with the binned scatter, the two key histograms of tf_binned_scatter
+        n_hist = (binned[0] + 8, binned[1] + 8) if (save_valid and binned is not None) else (0, 0)
+        spec = [("zero_block", n_ctr + n_hist[0] + n_hist[1], torch.int32), ("acc", R, torch.float32),
                 ("app_offset", R, torch.int32), ("app_count", R, torch.int32), ("val_count", R, torch.int32),
                 ("app_ray", cap, torch.int32), ("app_w", cap, torch.float32),
                 ("app_xyz", cap * 3, torch.float32), ("rgb", cap * 3, torch.float32)]
@@ -173,7 +177,7 @@ class _Workspace:
                 nkeys, kpe = max(binned[0], binned[1]), binned[2]
                 spec += [("ent_xyz", cap * 3, torch.float32), ("ent_df", cap, torch.float32),
                          ("binned", kpe * cap, torch.int32),
-                         ("bin_ints", 5 * (nkeys + 8) + kpe * cap // 256 + 64, torch.int32)]
+                         ("bin_ints", 4 * (nkeys + 8) + kpe * cap // 256 + 64, torch.int32)]
         if debug:
             spec += [("dbg_bbox", R * words * 2, torch.int32), ("dbg_valid", R * words * 2, torch.int32),
                      ("dbg_app", R * words * 2, torch.int32)]
@@ -183,6 +187,9 @@ class _Workspace:
         for name, n, dt in spec:
             setattr(self, name, self.buf[off:off + n * 4].view(dt))
             off += ((n * 4 + 255) // 256) * 256
+        self.counters = self.zero_block[:n_ctr]
+        self.hist_density = self.zero_block[n_ctr:n_ctr + n_hist[0]]
+        self.hist_app = self.zero_block[n_ctr + n_hist[0]:]
         self.R, self.N, self.seg_cap, self.cap, self.words = R, N, seg_cap, cap, words
         self.save_valid, self.debug, self.binned_cfg = save_valid, debug, binned
         self.busy = False
@@ -224,6 +231,7 @@ class TensorBase(nn.Module):
 
         # kernel-side options (not part of the reference interface)
         self.t_stop = 0.0              # early ray termination threshold on transmittance (0 = off)
+        self.count_samples = True      # False: forward() skips the num_valid_samples reduction (its 3rd result is then undefined)
         self.binned_scatter = True     # backward: counting-sorted LDS scatter (csrc/bin.hip) instead of per-tap atomics
         self.bin_tile, self.bin_bucket, self.bin_chunk = 8, 8, 512
         self._jitter_override = None   # tests: inject the stratified jitter instead of drawing it
@@ -377,23 +385,35 @@ class TensorBase(nn.Module):
             f.alpha_cells = None
         return f
 
-    def _packed(self, key, src, rows_pad, transpose=False):
-        """Zero-padded copy [rows_pad][kpad16(cols)] of a weight matrix (or its transpose
-        [kpad16(cols)][rows_pad]), refreshed when it changes."""
-        rows, cols = src.shape
-        kp = (cols + 15) // 16 * 16
-        tag = (src.data_ptr(), src._version, rows_pad, kp, transpose)
-        hit = self._pack_cache.get(key)
-        if hit is not None and hit[0] == tag and not torch.cuda.is_current_stream_capturing():
-            return hit[1]   # (while a graph is being captured the pack launch must be part of the graph)
-        shape = (kp, rows_pad) if transpose else (rows_pad, kp)
-        dst = hit[1] if hit is not None and tuple(hit[1].shape) == shape else \
-            torch.empty(shape, dtype=torch.float32, device=src.device)
-        s = src.detach().contiguous()
-        fn = H.lib().tf_pack_matrix_t if transpose else H.lib().tf_pack_matrix
-        H.check(fn(s.data_ptr(), rows, cols, dst.data_ptr(), rows_pad, _stream()), "tf_pack_matrix")
-        self._pack_cache[key] = (tag, dst)
-        return dst
+    def _packed_many(self, reqs):
+        """Zero-padded copies [rows_pad][kpad16(cols)] of weight matrices (or their transposes [kpad16(cols)][rows_pad]),
+        refreshed when the source changed — all stale ones in ONE tf_pack_matrices launch.  reqs: (key, src, rows_pad,
+        transpose)."""
+        out, todo = [], []
+        capturing = torch.cuda.is_current_stream_capturing()
+        for key, src, rows_pad, transpose in reqs:
+            rows, cols = src.shape
+            kp = (cols + 15) // 16 * 16
+            tag = (src.data_ptr(), src._version, rows_pad, kp, transpose)
+            hit = self._pack_cache.get(key)
+            if hit is not None and hit[0] == tag and not capturing:
+                out.append(hit[1])   # (while a graph is being captured the pack launch must be part of the graph)
+                continue
+            shape = (kp, rows_pad) if transpose else (rows_pad, kp)
+            dst = hit[1] if hit is not None and tuple(hit[1].shape) == shape else \
+                torch.empty(shape, dtype=torch.float32, device=src.device)
+            todo.append((src.detach().contiguous(), dst, rows, cols, rows_pad, transpose))
+            self._pack_cache[key] = (tag, dst)
+            out.append(dst)
+        for k0 in range(0, len(todo), H.PACK_MAX):
+            job = H.TfPackJob()
+            part = todo[k0:k0 + H.PACK_MAX]
+            job.n = len(part)
+            for it, (s_, dst, rows, cols, rows_pad, transpose) in zip(job.item, part):
+                it.src, it.dst, it.rows, it.cols, it.rows_pad, it.transpose = s_.data_ptr(), dst.data_ptr(), rows, cols, \
+                    rows_pad, int(transpose)
+            H.check(H.lib().tf_pack_matrices(C.byref(job), _stream()), "tf_pack_matrices")
+        return out
 
     def _pe_blocks(self, enc_mask, dev):
         """Order of the encoding blocks per head (models/mlp.py:41-66, 84-103, 126-153)."""
@@ -421,7 +441,8 @@ class TensorBase(nn.Module):
             blocks.append((src, freqs, mv))
         return blocks, keep
 
-    def _shade_desc(self, app_masks, enc_mask, dev, train=False):
+    def _shade_desc(self, app_masks, enc_mask, dev, train=False, pack=True):
+        """pack=False: dimensions only (size / support queries), no weight copies are made or refreshed."""
         s = H.TfShade()
         s.model = H.MODEL_CP if self._is_cp() else H.MODEL_VM
         s.grid = _i3(self._geom['grid'])
@@ -433,10 +454,12 @@ class TensorBase(nn.Module):
         nb = (self.app_dim + 15) // 16
         if nb > 4:
             raise H.HipError("app_dim > 64 is not supported by the shading kernel")
-        basis = self._packed('basis', self.basis_mat.weight, 16 * nb)
-        s.basis = basis.data_ptr()
-        keep.append(basis)
+        reqs = [('basis', self.basis_mat.weight, 16 * nb, False)]
         if self.shadingMode in ('SH', 'RGB'):
+            if pack:
+                basis, = self._packed_many(reqs)
+                s.basis = basis.data_ptr()
+                keep.append(basis)
             s.head = H.HEAD_SH if self.shadingMode == 'SH' else H.HEAD_RGB
             if self.shadingMode == 'SH' and self.app_dim != 27:
                 raise ValueError("SH shading needs app_dim == 27 (3 x 9 coefficients)")
@@ -453,16 +476,17 @@ class TensorBase(nn.Module):
         mlp = self.renderModule.mlp
         s.in_c = int(self.renderModule.in_mlpC)
         s.feature_c = int(self.featureC)
-        w1 = self._packed('w1', mlp[0].weight, self.featureC)
-        w2 = self._packed('w2', mlp[2].weight, self.featureC)
-        keep += [w1, w2]
+        if not pack:
+            return s, keep
+        reqs += [('w1', mlp[0].weight, self.featureC, False), ('w2', mlp[2].weight, self.featureC, False)]
         if train:     # the backward GEMMs dH1 = W2^T dZ2, dX = W1^T dZ1 read the transposes
-            w1t = self._packed('w1t', mlp[0].weight, self.featureC, transpose=True)
-            w2t = self._packed('w2t', mlp[2].weight, self.featureC, transpose=True)
-            keep += [w1t, w2t]
-            s.w1t, s.w2t = w1t.data_ptr(), w2t.data_ptr()
-        s.w1, s.b1 = w1.data_ptr(), mlp[0].bias.data_ptr()
-        s.w2, s.b2 = w2.data_ptr(), mlp[2].bias.data_ptr()
+            reqs += [('w1t', mlp[0].weight, self.featureC, True), ('w2t', mlp[2].weight, self.featureC, True)]
+        packed = self._packed_many(reqs)
+        keep += packed
+        s.basis, s.w1, s.w2 = packed[0].data_ptr(), packed[1].data_ptr(), packed[2].data_ptr()
+        if train:
+            s.w1t, s.w2t = packed[3].data_ptr(), packed[4].data_ptr()
+        s.b1, s.b2 = mlp[0].bias.data_ptr(), mlp[2].bias.data_ptr()
         s.w3, s.b3 = mlp[4].weight.data_ptr(), mlp[4].bias.data_ptr()
         return s, keep
 
@@ -531,7 +555,7 @@ class TensorBase(nn.Module):
                     binned = None
             extra = None
             if save_valid:
-                sh, _keep = self._shade_desc([None, None, None], None, dev)
+                sh, _keep = self._shade_desc([None, None, None], None, dev, pack=False)
                 if sh.head == H.HEAD_MLP and not H.lib().tf_shade_backward_supported(C.byref(sh)):
                     raise H.HipError(
                         f"training is not supported for this shading head: featureC={self.featureC} (64 / 128), "
@@ -588,7 +612,7 @@ class TensorBase(nn.Module):
         shade, keep = self._shade_desc(app_masks, enc_mask, dev, train=save_valid)
         ws = self._workspace(R, N, dev, save_valid)
         st = _stream()
-        ws.counters.zero_()
+        ws.zero_block.zero_()
 
         io = H.TfMarchIO()
         io.rays, io.n_rays, io.n_samples, io.ndc = rays.data_ptr(), R, N, int(bool(ndc_ray))

@@ -14,10 +14,14 @@ replays on the same stream, so no collective is ever inside a capture.
 
 Restrictions (else use the eager path): fixed batch size / N_samples, `white_bg=True` (the random background
 draw of tensorBase.py:380 is a host decision per step)."""
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
+from . import _hip as H
 from . import parallel
+from .field import _stream
 
 
 class GraphedTrainStep:
@@ -32,6 +36,7 @@ class GraphedTrainStep:
         self.target = torch.zeros(batch, 3, device=dev)
         self.jitter = torch.zeros(batch, device=dev)
         self.loss = torch.zeros((), device=dev)
+        self._grad_rgb = torch.zeros(batch, 3, device=dev)
         self.n_samples, self.mask, self.ndc = n_samples, mask, ndc_ray
         self.graph = None
         self._warm = max(1, warmup)   # >= 1: the first eager step also caches host copies of the geometry
@@ -40,12 +45,17 @@ class GraphedTrainStep:
         self._side = torch.cuda.Stream(device=dev)
 
     def _fwd_bwd(self):
-        rgb, _, _ = self.model(self.rays, self.mask, white_bg=True, is_train=True, ndc_ray=self.ndc,
-                               N_samples=self.n_samples)
-        loss = torch.mean((rgb - self.target) ** 2)
+        model = self.model
+        keep, model.count_samples = model.count_samples, False     # nobody reads num_valid_samples here
+        try:
+            rgb, _, _ = model(self.rays, self.mask, white_bg=True, is_train=True, ndc_ray=self.ndc, N_samples=self.n_samples)
+        finally:
+            model.count_samples = keep
+        # loss = mean((rgb - target)^2) (train.py:334) and d loss / d rgb in one launch instead of ~8 torch kernels
+        H.check(H.lib().tf_mse_grad(rgb.data_ptr(), self.target.data_ptr(), rgb.numel(), self.loss.data_ptr(),
+                                    self._grad_rgb.data_ptr(), _stream()), "tf_mse_grad")
         self.opt.zero_grad(set_to_none=True)
-        loss.backward()
-        self.loss.copy_(loss.detach())
+        rgb.backward(self._grad_rgb)
 
     def _body(self):
         self._fwd_bwd()
@@ -53,15 +63,19 @@ class GraphedTrainStep:
             parallel.allreduce_gradients(self.model)
         self.opt.step()
 
-    def _stage(self, rays, target):
-        self.rays.copy_(rays, non_blocking=True)
-        self.target.copy_(target, non_blocking=True)
-        j = torch.rand(rays.shape[0], 1, pin_memory=True)        # same CPU-generator draw as the reference
+    def _stage(self, rays, target, ids=None):
+        if ids is None:
+            self.rays.copy_(rays, non_blocking=True)
+            self.target.copy_(target, non_blocking=True)
+        else:       # gather the batch straight into the static buffers (allrays[ray_idx], train.py:298)
+            torch.index_select(rays, 0, ids, out=self.rays)
+            torch.index_select(target, 0, ids, out=self.target)
+        j = torch.rand(self.rays.shape[0], 1, pin_memory=True)   # same CPU-generator draw as the reference
         self.jitter.copy_(j.view(-1), non_blocking=True)
 
-    def step(self, rays, target):
-        """One optimisation step on (rays, target); returns the (device) loss tensor of that step."""
-        self._stage(rays, target)
+    def step(self, rays, target, ids=None):
+        """One optimisation step on (rays, target) — or on rows `ids` of them; returns the (device) loss tensor."""
+        self._stage(rays, target, ids)
         if hasattr(self.opt, "sync_lr") and self.opt._lr_dev is not None:
             self.opt.sync_lr()                                    # FusedAdam: lr schedule follows the host values
         if self.graph is not None:

@@ -50,7 +50,8 @@ class FusedAdam(torch.optim.Optimizer):
             total += (p.numel() + 63) // 64 * 64
         m = torch.zeros(total, device=dev)
         v = torch.zeros(total, device=dev)
-        self._step_dev = torch.zeros((), device=dev)
+        self._step_dev = torch.zeros((), device=dev)           # completed updates
+        self._arrivals = torch.zeros(1, dtype=torch.int32, device=dev)
         for (gi, p), o in zip(ps, offs):
             st = self.state[p]
             st['step'] = self._step_dev
@@ -88,7 +89,7 @@ class FusedAdam(torch.optim.Optimizer):
             self._init_state(ps)
         self.sync_lr()
         m, v, offs, _ = self._flat
-        self._step_dev += 1
+        one_launch = len(ps) <= H.ADAM_MAX_SEG       # then the kernel advances the step count itself
         g0 = self.param_groups[0]
         lib, st = H.lib(), _stream()
         for s0 in range(0, len(ps), H.ADAM_MAX_SEG):
@@ -109,7 +110,11 @@ class FusedAdam(torch.optim.Optimizer):
             job.n_seg = len(part)
             job.lrs, job.step = self._lr_dev.data_ptr(), self._step_dev.data_ptr()
             job.beta1, job.beta2, job.eps = g0['betas'][0], g0['betas'][1], g0['eps']
+            if one_launch:
+                job.step_rw, job.arrivals = self._step_dev.data_ptr(), self._arrivals.data_ptr()
             H.check(lib.tf_adam_step(C.byref(job), st), "tf_adam_step")
+        if not one_launch:
+            self._step_dev += 1
         for _, p in ps:      # the kernel wrote the parameters behind autograd's back: caches keyed on ._version
             torch.autograd.graph.increment_version(p)       # (packed weight copies, field.py) must see the change
         return loss

@@ -220,8 +220,7 @@ def main():
                      is_train=False)
 
     def graph_step(i):
-        ids = parallel.shard_ids(perm[i], rank, world)
-        return graphed.step(rays[ids], targets[ids])
+        return graphed.step(rays, targets, parallel.shard_ids(perm[i], rank, world))
 
     step = (graph_step if use_graph else train_step) if args.mode == "train" else eval_step
     # the scene set-up leaves ~10^6 long-lived Python objects behind; without this the cyclic collector re-walks
@@ -244,6 +243,7 @@ def main():
         step(i)
         if not use_graph:
             ctr_sum += model.last["ws"].counters2d[:, :3].sum(0)
+    host_issue = time.perf_counter() - t0        # host time to enqueue the timed steps (diagnostic: host- vs GPU-bound)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -312,7 +312,7 @@ def main():
                        "launch": ("hipGraph replay" if world == 1 else "2 hipGraph replays around one RCCL all-reduce")
                                  if use_graph else "eager",
                        "optimizer": "torch.optim.Adam(fused)" if args.torch_adam else "Adam, one launch (tf_adam_step)",
-                       "eager_ms_per_step": eager_ms},
+                       "eager_ms_per_step": eager_ms, "host_issue_ms_per_step": host_issue / k * 1e3},
             "roofline": roof,
             "kernels": {n: {"avg_ms": round(v["avg_ms"], 5), "GBps": round(v["GBps"], 1),
                             "TFLOPps": round(v["TFLOPps"], 2)} for n, v in kt.items()},

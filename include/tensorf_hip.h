@@ -153,6 +153,24 @@ int tf_pack_alpha_cells(const float* volume, int gx, int gy, int gz, uint8_t* ce
 int tf_pack_matrix(const float* src, int rows, int cols, float* dst, int rows_pad, tf_stream_t stream);
 /* dst[c][r] = src[r][c], dst is (kpad(cols), rows_pad) zero padded: the transposes the backward GEMMs read. */
 int tf_pack_matrix_t(const float* src, int rows, int cols, float* dst, int rows_pad, tf_stream_t stream);
+/* Several of those copies in ONE launch (the training step refreshes basis, w1, w2, w1^T, w2^T after every
+ * optimizer step): item k writes dst = padded copy of src (rows x cols), or its transpose. */
+#define TF_PACK_MAX 8
+typedef struct TfPackItem {
+    const float* src;
+    float* dst;
+    int rows, cols, rows_pad, transpose;
+} TfPackItem;
+typedef struct TfPackJob {
+    int n;
+    int pad_;
+    TfPackItem item[TF_PACK_MAX];
+} TfPackJob;
+int tf_pack_matrices(const TfPackJob* job, tf_stream_t stream);
+
+/* The photometric loss of train.py:334 and its gradient in one launch: *loss = mean((a - b)^2) over n floats,
+ * grad[i] = 2 (a[i] - b[i]) / n.  (Used by the hipGraph-captured step; eager callers keep their torch expression.) */
+int tf_mse_grad(const float* a, const float* b, int n, float* loss, float* grad, tf_stream_t stream);
 
 /* sample_ray / sample_ray_ndc + bbox test + AlphaGridMask test + compute_densityfeature +
  * feature2density + raw2alpha + app_mask + acc/depth reductions:
@@ -239,10 +257,11 @@ typedef struct TfBinJob {
     const float* grad;        /* density: (cap) dL/df per entry; appearance: (cap, ld) dL/dV rows */
     int grad_ld;              /* 0: one scalar per entry, broadcast over components; else row stride */
     int tile, bucket, chunk;  /* T, LB, max entries per workgroup */
-    /* workspace (ints): hist[nkeys], offsets[nkeys+1], cursor[nkeys], chunk_off[nkeys+1] followed by the
+    /* workspace (ints): hist[nkeys] (read, then left as is), offsets[nkeys+1], cursor[nkeys], chunk_off[nkeys+1] followed by the
      * work-item table (nkeys + kpe*entries/chunk ints); binned[kpe*entries], kpe = tf_bin_keys_per_entry */
     int* hist; int* offsets; int* cursor; int* chunk_off; int* binned;
     int nkeys;
+    int hist_zeroed;          /* 1: the caller has zeroed hist[0..nkeys) on this stream (saves a launch) */
 } TfBinJob;
 #define TF_BIN_MAX_KEYS 262144  /* tf_binned_scatter returns hipErrorInvalidValue above this (the sort walks the keys in
                                  * LDS-sized ranges of 16384; ~1000^3 grids at 48 components stay below) */
@@ -278,7 +297,11 @@ int tf_regularizers(const TfRegJob* job, tf_stream_t stream);
  * storage order: p, g (its gradient, same layout), m / v (first / second moment), n elements, `group` selects
  * the learning rate lrs[group] (train.py uses two: lr_init for the factor tensors, lr_basis for the networks).
  * chunk_end[s] = number of TF_ADAM_CHUNK-element chunks in segments 0..s (one workgroup per chunk).
- * `lrs` and `step` are DEVICE pointers (float): step holds the 1-based step count t of this update. */
+ * `lrs` and `step` are DEVICE pointers (float).  *step is the number of COMPLETED updates: this launch is update
+ * t = *step + 1.  With `arrivals` (one zeroed device uint) the kernel advances the count itself: the last workgroup
+ * to finish writes *step_rw = *step + 1 (step_rw == step) and re-arms the counter; with arrivals == NULL the caller
+ * advances *step after the launch.  Launches that share `step` must cover all segments in ONE launch (<= 32) to use
+ * `arrivals`. */
 #define TF_ADAM_MAX_SEG 32
 #define TF_ADAM_CHUNK 8192
 typedef struct TfAdamSeg {
@@ -298,6 +321,8 @@ typedef struct TfAdamJob {
     const float* lrs;
     const float* step;
     double beta1, beta2, eps;
+    float* step_rw;           /* == step, writable (used with arrivals) */
+    unsigned int* arrivals;   /* NULL, or a zeroed device counter */
 } TfAdamJob;
 int tf_adam_step(const TfAdamJob* job, tf_stream_t stream);
 
