@@ -75,6 +75,12 @@ class TfBinJob(C.Structure):
                 ("nkeys", C.c_int), ("hist_zeroed", C.c_int)]
 
 
+class TfCamera(C.Structure):
+    _fields_ = [("height", C.c_int), ("width", C.c_int), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float), ("c2w", C.c_float * 12), ("opengl", C.c_int), ("normalize", C.c_int), ("ndc", C.c_int),
+                ("ndc_near", C.c_float)]
+
+
 PACK_MAX = 8
 
 
@@ -119,6 +125,7 @@ _SIGS = {
     "tf_pack_matrix_t": [_fp, C.c_int, C.c_int, _fp, C.c_int, _fp],
     "tf_pack_matrices": [C.POINTER(TfPackJob), _fp],
     "tf_mse_grad": [_fp, _fp, C.c_int, _fp, _fp, _fp],
+    "tf_generate_rays": [C.POINTER(TfCamera), _fp, C.c_longlong, C.c_int, _fp, _fp],
     "tf_march_forward": [C.POINTER(TfField), C.POINTER(TfMarchIO), _fp],
     "tf_shade_forward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp],
     "tf_composite_forward": [C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp],

@@ -104,9 +104,69 @@ __global__ __launch_bounds__(64) void filter_rays_kernel(const TfField F, const 
     if (lane == 0) keep[r] = any;
 }
 
+// Camera rays for a list (or a contiguous range) of pixels.  dataLoader/ray_utils.py:24-63
+// (pixel centre + 0.5, ((i - cx) / fx, +-(j - cy) / fy, +-1)), :66-87 (rays_d = dir @ c2w[:3,:3]^T, rays_o =
+// c2w[:3,3]), dataLoader/blender.py:59 (directions normalised before the rotation), ray_utils.py:90-107 (NDC).
+__global__ __launch_bounds__(256) void generate_rays_kernel(const TfCamera cam, const long long* __restrict__ ids,
+                                                            long long first, int n, float* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const long long pix = ids ? ids[t] : first + t;
+    const int j = (int)(pix / cam.width), i = (int)(pix - (long long)j * cam.width);
+    float d[3];
+    d[0] = ((float)i + 0.5f - cam.cx) / cam.fx;
+    d[1] = ((float)j + 0.5f - cam.cy) / cam.fy;
+    d[2] = 1.f;
+    if (cam.opengl) {      // get_ray_directions_blender: y up, looking down -z
+        d[1] = -d[1];
+        d[2] = -1.f;
+    }
+    if (cam.normalize) {
+        float q = d[0] * d[0];
+        q = q + d[1] * d[1];
+        q = q + d[2] * d[2];
+        const float nrm = sqrtf(q);
+        d[0] = d[0] / nrm; d[1] = d[1] / nrm; d[2] = d[2] / nrm;
+    }
+    float o[3], w[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float* row = cam.c2w + 4 * r;
+        float acc = d[0] * row[0];
+        acc = acc + d[1] * row[1];
+        acc = acc + d[2] * row[2];
+        w[r] = acc;
+        o[r] = row[3];
+    }
+    if (cam.ndc) {         // ndc_rays_blender
+        const float tt = -(cam.ndc_near + o[2]) / w[2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) o[r] = o[r] + tt * w[r];
+        const float sx = -1.f / (cam.width / (2.f * cam.fx)), sy = -1.f / (cam.height / (2.f * cam.fy));
+        const float o0 = sx * o[0] / o[2], o1 = sy * o[1] / o[2], o2 = 1.f + 2.f * cam.ndc_near / o[2];
+        const float d0 = sx * (w[0] / w[2] - o[0] / o[2]), d1 = sy * (w[1] / w[2] - o[1] / o[2]);
+        const float d2 = -2.f * cam.ndc_near / o[2];
+        o[0] = o0; o[1] = o1; o[2] = o2;
+        w[0] = d0; w[1] = d1; w[2] = d2;
+    }
+    float* r6 = out + (size_t)t * 6;
+    r6[0] = o[0]; r6[1] = o[1]; r6[2] = o[2];
+    r6[3] = w[0]; r6[4] = w[1]; r6[5] = w[2];
+}
+
 }  // namespace
 
 extern "C" {
+
+int tf_generate_rays(const TfCamera* cam, const long long* pixel_ids, long long first_pixel, int n, float* rays_out,
+                     tf_stream_t stream) {
+    if (n <= 0) return 0;
+    if (cam->width < 1 || cam->height < 1 || cam->fx == 0.f || cam->fy == 0.f) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(generate_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *cam, pixel_ids,
+                       first_pixel, n, rays_out);
+    return TF_CHECK_LAUNCH();
+}
+
 
 int tf_alpha_points(const TfField* field, const float* xyz, int n, float length, float* out_alpha, tf_stream_t stream) {
     if (n <= 0) return 0;

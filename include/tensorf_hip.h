@@ -236,6 +236,24 @@ int tf_sample_alpha_points(const float* volume, int gx, int gy, int gz, const fl
 int tf_filter_rays(const TfField* field, const float* rays, int n_rays, int bbox_only, int n_samples, uint8_t* keep,
                    tf_stream_t stream);
 
+/* ---- on-device ray generation ----------------------------------------------------------
+ * rays_out[t] = (origin, direction) of pixel pixel_ids[t] (or first_pixel + t when pixel_ids is NULL), pixels
+ * numbered row-major j * width + i.  Camera-space direction ((i + 0.5 - cx) / fx, (j + 0.5 - cy) / fy, 1)
+ * (dataLoader/ray_utils.py:24-42) or, with opengl, (.., -(..), -1) (:45-63); optionally normalised
+ * (dataLoader/blender.py:59); rotated by the 3x4 camera-to-world matrix (row-major c2w[12], ray_utils.py:66-87);
+ * optionally projected to NDC with near plane ndc_near (ray_utils.py:90-107). */
+typedef struct TfCamera {
+    int height, width;
+    float fx, fy, cx, cy;
+    float c2w[12];
+    int opengl;
+    int normalize;
+    int ndc;
+    float ndc_near;
+} TfCamera;
+int tf_generate_rays(const TfCamera* cam, const long long* pixel_ids, long long first_pixel, int n, float* rays_out,
+                     tf_stream_t stream);
+
 /* Binned ("owner computes") scatter of the VM factor gradients — the backward of the plane x line lookups
  * (autograd of tensoRF.py:216-225 / :240-260) without one global atomic per tap.
  * Global float atomics on random 64-B pieces are request-bound (~0.4 TB/s measured), so the samples are first

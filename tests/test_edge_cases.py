@@ -86,3 +86,35 @@ def test_training_step_without_shaded_samples(recon):
     opt.step()
     for k, v in model.state_dict().items():
         assert torch.equal(v, before[k]), k
+
+
+def test_generated_rays_match_the_loader_formulas(recon):
+    """tf_generate_rays against the torch expressions of dataLoader/ray_utils.py (restated here: the module itself
+    needs kornia and cannot be imported, so this row's parity is unpinned against the reference's own output)."""
+    from recon_amd import synthetic as S
+    H_, W_, f = 37, 53, 61.5
+    g = torch.Generator().manual_seed(2)
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+    c2w = torch.cat([q, torch.randn(3, 1, generator=g)], 1)
+    j, i = torch.meshgrid(torch.arange(H_, dtype=torch.float32), torch.arange(W_, dtype=torch.float32), indexing="ij")
+    # (1) OpenCV-style camera, unit directions (Blender loader), whole image and a pixel subset
+    dirs = torch.stack([(i + 0.5 - W_ / 2) / f, (j + 0.5 - H_ / 2) / f, torch.ones_like(i)], -1)
+    dirs = dirs / torch.norm(dirs, dim=-1, keepdim=True)
+    ref = torch.cat([c2w[:, 3].expand(H_ * W_, 3), dirs.view(-1, 3) @ c2w[:, :3].T], 1)
+    out = recon.generate_rays(H_, W_, f, c2w, device=DEV)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=2e-6, atol=2e-6)
+    ids = torch.randperm(H_ * W_, generator=g)[:500]
+    out = recon.generate_rays(H_, W_, f, c2w, pixel_ids=ids, device=DEV)
+    np.testing.assert_allclose(out.cpu().numpy(), ref[ids].numpy(), rtol=2e-6, atol=2e-6)
+    # (2) OpenGL-style camera, principal point off centre, no normalisation, NDC projection (forward-facing scenes)
+    c2w2 = torch.cat([torch.eye(3) + 0.02 * torch.randn(3, 3, generator=g), 0.1 * torch.randn(3, 1, generator=g)], 1)
+    cx, cy = 25.0, 19.5
+    dirs = torch.stack([(i + 0.5 - cx) / f, -(j + 0.5 - cy) / (1.1 * f), -torch.ones_like(i)], -1).view(-1, 3)
+    o, d = S.ndc_project(H_, W_, f, 1.0, c2w2[:, 3].expand(H_ * W_, 3), dirs @ c2w2[:, :3].T)
+    out = recon.generate_rays(H_, W_, (f, 1.1 * f), c2w2, center=(cx, cy), normalize=False, opengl=True, ndc_near=1.0,
+                              device=DEV)
+    # the loader's projection takes ONE focal length; with fy = 1.1 fx the kernel's y scale (2 fy / H) is 1.1 x its
+    ref2 = torch.cat([o, d], 1)
+    got = out.cpu()
+    np.testing.assert_allclose(got[:, [0, 2, 3, 5]].numpy(), ref2[:, [0, 2, 3, 5]].numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got[:, [1, 4]].numpy(), 1.1 * ref2[:, [1, 4]].numpy(), rtol=1e-5, atol=1e-5)
