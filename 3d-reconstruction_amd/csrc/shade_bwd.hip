@@ -10,11 +10,10 @@
 //     dX  = W1^T dZ1             (in place of X)   dfeat = dX[:, :D] + PE'(feat) . dX[:, PE cols]
 //     dB += dfeat^T V                               dV = B^T dfeat (in place of V)
 //     dP / dL scatter-add with float atomics (4 lanes per sample, channel-last gradients).
-// The weight-gradient GEMMs (sample index = MFMA k dimension) accumulate into a per-workgroup SLAB in global
-// memory (L2 / Infinity-Cache resident, accumulator-fragment order: one 16-B load + store per lane and 16x16
-// tile and sample tile), summed over workgroups by wslab_reduce_kernel.  Nothing but six scalars lives in
-// registers across tiles, which keeps the kernel at 2 waves per SIMD without scratch (kernels that spill
-// cannot be replayed from a hipGraph on this stack).
+// The weight-gradient GEMMs (sample index = MFMA k dimension) accumulate in REGISTERS across the tiles of a
+// workgroup (104 VGPRs per lane at 2 waves per SIMD, no scratch: kernels that spill cannot be replayed from a
+// hipGraph on this stack) and are written once, in accumulator-fragment order, to the workgroup's slab in global
+// memory; wslab_reduce_kernel sums the slabs over the workgroups.
 #include "tf_shade.h"
 
 using namespace tf;
@@ -124,6 +123,21 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
     float* slabB = slabW1 + FT * kt1 * 256;
     bool first = true;
     float aW3[3] = {0.f, 0.f, 0.f}, ab2 = 0.f, ab1 = 0.f, ab3 = 0.f;
+    // The weight-gradient GEMMs (dW2, dW1, dB: sample index = MFMA k dimension) accumulate in registers across the
+    // tiles of this workgroup — 104 VGPRs per lane — and reach the workgroup's slab once, at the end.  (Variants
+    // measured: all three through per-tile slab round trips 411 us, dW1 alone through the slab 402 us, none 392 us;
+    // fetching a phase's weight fragments ahead of its MFMA loop on top of this does not fit the register file.)
+    f32x4 aW2[1][NW2];
+    zero_acc(aW2);
+    f32x4 aW1[KT1S];                 // dW1: k tiles my_sg, my_sg + SG, ... of feature tile my_ft
+#pragma unroll
+    for (int q = 0; q < KT1S; ++q) aW1[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int KTBW = 3;          // dB: column tiles wave, wave + 8, wave + 16 (n_app_total <= 384)
+    f32x4 aB[KTBW][NB][1];
+#pragma unroll
+    for (int k = 0; k < KTBW; ++k)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) aB[k][i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     if (src.counters) {
         if (tid == 0) {
@@ -156,7 +170,6 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         int s1, n1;
         if (tid < M && locate_tile(src, pre, (int)blockIdx.x, s1, n1)) fetch_info(s1, n1, tid);
     }
-    const bool quads = vm_quads_ok(S);
 
     TF_T0();
     for (int t = blockIdx.x;; t += gridDim.x) {
@@ -198,8 +211,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
             const int smp = wave * 8 + (lane >> 3), sub = lane & 7;
             float u[3] = {ixyz[smp * 3], ixyz[smp * 3 + 1], ixyz[smp * 3 + 2]};
             float* vrow = V + smp * L.sv;
-            if (quads) app_products_vm_batched<5>(S, u, sub, 8, vrow);
-            else app_products(S, u, sub, vrow, 8);
+            app_products(S, u, sub, vrow, 8);
             for (int c = S.n_app_total + sub; c < kpB; c += 8) vrow[c] = 0.f;
         }
         lds_barrier();
@@ -327,18 +339,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         lds_barrier();
         TF_MARK(1);
         {   // dW2[f2][f1] += sum_s dZ2[s][f2] H1[s][f1]
-            // the slab's running sum is fetched now and added after the MFMA loop: its latency hides behind the loop
-            f32x4 aW2[1][NW2], run[NW2];
-#pragma unroll
-            for (int j = 0; j < NW2; ++j) {
-                float* sp = slabW2 + ((size_t)(my_ft * FT + NW2 * my_sg + j) * 64 + lane) * 4;
-                run[j] = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(sp);
-            }
-            zero_acc(aW2);
             mma_gen<1, NW2, COL, COL>(H2, L.sh, 16 * my_ft, H1, L.sh, 16 * NW2 * my_sg, M / 16, aW2, lane);
-#pragma unroll
-            for (int j = 0; j < NW2; ++j)
-                *reinterpret_cast<f32x4*>(slabW2 + ((size_t)(my_ft * FT + NW2 * my_sg + j) * 64 + lane) * 4) = aW2[0][j] + run[j];
         }
         lds_barrier();   // every wave is done reading H1 for dW2
         TF_MARK(2);
@@ -365,37 +366,29 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
             ab1 += a;
         }
         // dW1[f][k] += sum_s dZ1[s][f] X[s][k]: dZ1 fragments are read once per k-group and reused for every k tile
-        // this wave owns (k tiles my_sg, my_sg + SG, ...)
+        // this wave owns (k tiles my_sg, my_sg + SG, ...); the accumulators live in registers across tiles
 #pragma unroll 1
-        for (int half = 0; half < 2; ++half) {      // two passes over the k tiles: half the accumulator registers
-            constexpr int KH = KT1S / 2;
-            f32x4 aW1[KH], run[KH];
+        for (int kg = 0; kg < M / 16; ++kg) {
+            const int ks = 16 * kg + 4 * lg;
+            const f32x4 a = ldfrag<COL>(H1, L.sh, 16 * my_ft + lc, ks);
+            // GQ k tiles at a time: their MFMA chains interleave (a chain of four dependent MFMAs per tile would wait
+            // on its own accumulator)
+            constexpr int GQ = KT1S % 4 == 0 ? 4 : 2;
+            static_assert(KT1S % GQ == 0, "k tiles per wave come in groups");
 #pragma unroll
-            for (int q = 0; q < KH; ++q) {
-                const int j = my_sg + SG * (half * KH + q);
-                run[q] = (first || j >= kt1) ? (f32x4){0.f, 0.f, 0.f, 0.f}
-                                             : *reinterpret_cast<const f32x4*>(slabW1 + ((size_t)(my_ft * kt1 + j) * 64 + lane) * 4);
-                aW1[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll 1
-            for (int kg = 0; kg < M / 16; ++kg) {
-                const int ks = 16 * kg + 4 * lg;
-                const f32x4 a = ldfrag<COL>(H1, L.sh, 16 * my_ft + lc, ks);
+            for (int q0 = 0; q0 < KT1S; q0 += GQ) {
+                f32x4 b[GQ];
 #pragma unroll
-                for (int q = 0; q < KH; ++q) {
-                    const int j = my_sg + SG * (half * KH + q);
-                    if (j < kt1) {
-                        const f32x4 b = ldfrag<COL>(X, L.sx, 16 * j + lc, ks);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            aW1[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], aW1[q], 0, 0, 0);
-                    }
+                for (int g = 0; g < GQ; ++g) {
+                    const int j = my_sg + SG * (q0 + g);
+                    b[g] = j < kt1 ? ldfrag<COL>(X, L.sx, 16 * j + lc, ks) : (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
-            }
 #pragma unroll
-            for (int q = 0; q < KH; ++q) {
-                const int j = my_sg + SG * (half * KH + q);
-                if (j < kt1) *reinterpret_cast<f32x4*>(slabW1 + ((size_t)(my_ft * kt1 + j) * 64 + lane) * 4) = aW1[q] + run[q];
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int g = 0; g < GQ; ++g)
+                        if (my_sg + SG * (q0 + g) < kt1)
+                            aW1[q0 + g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[g][e], aW1[q0 + g], 0, 0, 0);
             }
         }
         lds_barrier();   // dW1 finished reading X; the H2 region (dZ2) is free
@@ -403,14 +396,17 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         for (int smp = wave; smp < M; smp += NW)             // feat copy for the PE derivative
             if (lane < S.app_dim) Fs[smp * L.sf + lane] = X[smp * L.sx + lane];
         lds_barrier();
-        // dX[k][s] = sum_f W1[f][k] dZ1[s][f], written in place of X; wave w owns k tiles w, w+8, ...
-        for (int kt = wave; kt < kt1; kt += NW) {
-            f32x4 acc[1][4];
+        // dX[k][s] = sum_f W1[f][k] dZ1[s][f], written in place of X.  Work items are (k tile, pair of sample tiles):
+        // 2 kt1 items dealt round-robin, so that e.g. 10 k tiles load the 8 waves evenly (whole k tiles would give two
+        // waves twice the work)
+        for (int it = wave; it < 2 * kt1; it += NW) {
+            const int kt = it >> 1, sp = it & 1;
+            f32x4 acc[1][2];
             zero_acc(acc);
-            mma_block<1, 4>(S.w1t, FC, 16 * kt, H1, L.sh, 0, FC / 16, acc, lane);
+            mma_block<1, 2>(S.w1t, FC, 16 * kt, H1, L.sh, 32 * sp, FC / 16, acc, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<f32x4*>(X + (16 * j + lc) * L.sx + 16 * kt + 4 * lg) = acc[0][j];
+            for (int j = 0; j < 2; ++j)
+                *reinterpret_cast<f32x4*>(X + (32 * sp + 16 * j + lc) * L.sx + 16 * kt + 4 * lg) = acc[0][j];
         }
         lds_barrier();
         TF_MARK(5);
@@ -429,9 +425,11 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                             const float* mk = S.pe[b].mask;
                             const float v = Fs[smp * L.sf + d];
                             float fr = 1.f;
+                            const bool big = !(ldexpf(fabsf(v), F - 1) < 8192.f);
                             for (int k = 0; k < F; ++k) {
                                 float sn, cs;
-                                pe_sincos(v * fr, &sn, &cs);
+                                if (__builtin_expect(big, 0)) pe_sincos(v * fr, &sn, &cs);
+                                else pe_sincos_fast(v * fr, &sn, &cs);
                                 const int ci = d * F + k;
                                 const float ms = mk ? mk[ci] : 1.f, mc = mk ? mk[D * F + ci] : 1.f;
                                 gsum += dx[off + ci] * (cs * fr * ms);
@@ -446,18 +444,11 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
             }
         }
         lds_barrier();
-        // dB[f][c] += sum_s dfeat[s][f] V[s][c]; wave w owns column tiles w, w+8, ...
-        for (int ct = wave; ct < ktB; ct += NW) {
-            f32x4 one[NB][1], run[NB];
+        // dB[f][c] += sum_s dfeat[s][f] V[s][c]; wave w owns column tiles w, w+8, w+16 (register accumulators)
 #pragma unroll
-            for (int i = 0; i < NB; ++i)
-                run[i] = first ? (f32x4){0.f, 0.f, 0.f, 0.f}
-                               : *reinterpret_cast<const f32x4*>(slabB + ((size_t)(i * ktB + ct) * 64 + lane) * 4);
-            zero_acc(one);
-            mma_gen<NB, 1, COL, COL>(Fd, L.sf, 0, V, L.sv, 16 * ct, M / 16, one, lane);
-#pragma unroll
-            for (int i = 0; i < NB; ++i)
-                *reinterpret_cast<f32x4*>(slabB + ((size_t)(i * ktB + ct) * 64 + lane) * 4) = one[i][0] + run[i];
+        for (int k = 0; k < KTBW; ++k) {
+            const int ct = wave + NW * k;
+            if (ct < ktB) mma_gen<NB, 1, COL, COL>(Fd, L.sf, 0, V, L.sv, 16 * ct, M / 16, aB[k], lane);
         }
         lds_barrier();   // dB finished reading V
         // dV[c][s] = sum_f B[f][c] dfeat[s][f], written in place of V
@@ -481,6 +472,28 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
     }
     TF_FLUSH();
 
+    if (!first) {      // this workgroup owned at least one tile: its register-resident weight gradients go to the slab
+        int tid3 = threadIdx.x;
+        asm volatile("" : "+v"(tid3));
+        const int wave = tid3 >> 6, lane = tid3 & 63, my_ft = wave % FT, my_sg = wave / FT;
+#pragma unroll
+        for (int j = 0; j < NW2; ++j)
+            *reinterpret_cast<f32x4*>(slabW2 + ((size_t)(my_ft * FT + NW2 * my_sg + j) * 64 + lane) * 4) = aW2[0][j];
+#pragma unroll
+        for (int q = 0; q < KT1S; ++q) {
+            const int j = my_sg + SG * q;
+            if (j < kt1) *reinterpret_cast<f32x4*>(slabW1 + ((size_t)(my_ft * kt1 + j) * 64 + lane) * 4) = aW1[q];
+        }
+#pragma unroll
+        for (int k = 0; k < KTBW; ++k) {
+            const int ct = wave + NW * k;
+            if (ct < ktB) {
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+                    *reinterpret_cast<f32x4*>(slabB + ((size_t)(i * ktB + ct) * 64 + lane) * 4) = aB[k][i][0];
+            }
+        }
+    }
     // ================= the per-feature scalars (the GEMM gradients are in the slab) =================
     {
         int tid2 = threadIdx.x;
