@@ -26,7 +26,7 @@ def stats(d, last):
     steps = min((len(v) for k, v in per.items() if "adam_kernel" in k or "shade_backward" in k), default=0)
     for k, v in per.items():
         v.sort()
-        per_step = max(1, round(len(v) / steps)) if steps else 1      # e.g. the scatter kernels run twice per step
+        per_step = len(v) // steps if steps and len(v) % steps == 0 else 1   # e.g. the scatter kernels run twice per step
         dur = [x[1] for x in (v[-last * per_step:] if last and _ours(k) else v)]
         rows.append((sum(dur), k, len(dur), sum(dur) / len(dur), min(dur), max(dur)))
     rows.sort(reverse=True)
