@@ -71,6 +71,8 @@ class _RenderFn(torch.autograd.Function):
         n_rep = 0 if binned else N_REP
         grads, flat, offs, grad_len, line_len = _grad_buffers(named, n_rep)
         model.grad_flat = flat[:grad_len]   # every gradient of this step, one contiguous buffer (parallel.py)
+        if getattr(model, "grad_layout", None) is None or model.grad_layout[0] != offs:
+            model.grad_layout = (offs, grad_len)     # name -> offset (floats): parallel.gradient_support
         if g_rgb is None:
             g_rgb = torch.zeros(ws.R, 3, dtype=torch.float32, device=ctx.params[0].device)
         g = g_rgb.detach().to(torch.float32).contiguous()

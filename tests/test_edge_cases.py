@@ -118,3 +118,37 @@ def test_generated_rays_match_the_loader_formulas(recon):
     got = out.cpu()
     np.testing.assert_allclose(got[:, [0, 2, 3, 5]].numpy(), ref2[:, [0, 2, 3, 5]].numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(got[:, [1, 4]].numpy(), 1.1 * ref2[:, [1, 4]].numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("scene", ["C2_vm300", "C4_ndc", "C5_tt640", "shrunk"])
+def test_gradient_support_bounds_the_real_gradients(recon, scene):
+    """parallel.gradient_support (what the data-parallel all-reduce exchanges) against the kernels: every entry of the
+    gradient buffer outside the reported segments is exactly zero after a real training backward."""
+    from recon_amd import parallel
+    from tests.test_full_size import _scene
+    if scene == "shrunk":       # mask aabb != model aabb, off-centre occupancy
+        from recon_amd import synthetic as S
+        torch.manual_seed(0)
+        aabb = torch.tensor([[-1.2, -0.9, -1.4], [1.0, 1.3, 0.8]], device=DEV)
+        model = recon.TensorVMSplit(S.lego_args(), aabb, [96, 80, 112], S.LEGO_NEAR_FAR, DEV)
+        S.make_trained_like(model, recon.AlphaGridMask, mask_res=48, radius=0.5)
+        vol = model.alphaMask.alpha_volume[0, 0].clone()
+        vol[:, :, 30:] = 0                     # keep the low-x half of the ball only
+        model.alphaMask = recon.AlphaGridMask(DEV, torch.tensor([[-1.5] * 3, [1.5] * 3], device=DEV), vol)
+        rays, N, ndc = S.blender_rays(1)[::37][:4096].to(DEV).contiguous(), 300, False
+    else:
+        model, rays, N, ndc, _ = _scene(recon, scene)
+    torch.manual_seed(1)
+    rgb, _, _ = model(rays, None, white_bg=True, is_train=True, ndc_ray=ndc, N_samples=N)
+    (rgb ** 2).mean().backward()
+    segs = parallel.gradient_support(model)
+    assert segs is not None, "the scene's alpha mask leaves most plane rows empty"
+    flat = model.grad_flat
+    inside = torch.zeros(flat.numel(), dtype=torch.bool, device=DEV)
+    for a, b in segs:
+        inside[a:b] = True
+    frac = float(inside.float().mean())
+    assert float(flat.abs().sum()) > 0 and frac < 0.9
+    assert float(flat[~inside].abs().max()) == 0.0, "a gradient entry outside the exchanged support is non-zero"
+    # tightness: the outermost exchanged rows of the largest plane are within a few rows of real data
+    print(scene, f"support = {frac:.2%} of the gradient buffer, {len(segs)} segments")

@@ -59,8 +59,44 @@ def _worker(rank, world, port, q):
     model2.grad_flat = flat
     parallel.allreduce_gradients(model2)
     ok_flat = torch.allclose(flat, torch.arange(10, dtype=torch.float32) * (1 + 2) / 2)
+    # 4. support-limited exchange: with an alpha mask only the plane rows that can receive gradient travel; the
+    #    result must equal the full all-reduce (gradients are exactly zero outside the support on every rank)
+    torch.manual_seed(0)
+    model = recon_amd.TensorVMSplit(dict(step_ratio=0.5, fea2denseAct="softplus", density_n_comp=[4, 4, 4],
+                                         app_n_comp=[8, 8, 8], app_dim=27, density_shift=-10.0, distance_scale=25.0,
+                                         alphaMask_thres=0.001, shadingMode="MLP_Fea", pos_pe=2, view_pe=2, fea_pe=2,
+                                         featureC=64),
+                                    torch.tensor([[-1.5] * 3, [1.5] * 3]), [40, 44, 36], [2.0, 6.0], "cpu")
+    vol = torch.zeros(17, 17, 17)
+    vol[6:9, 5:8, 7:11] = 1.0
+    model.alphaMask = recon_amd.AlphaGridMask("cpu", model.aabb, vol)
+    named = sorted(model.named_parameters(), key=lambda kv: 0 if "_line." in kv[0] else 1)
+    offs, total = {}, 0
+    for k, p in named:
+        offs[k] = total
+        total += (p.numel() + 63) // 64 * 64
+    flat3 = torch.zeros(total)
+    model.grad_flat, model.grad_layout = flat3, (offs, total)
+    for k, p in named:
+        chunk = flat3[offs[k]:offs[k] + p.numel()]
+        if p.dim() == 4:
+            b, c, h, w = p.shape
+            p.grad = chunk.view(b, h, w, c).permute(0, 3, 1, 2)
+        else:
+            p.grad = chunk.view(p.shape)
+    segs = parallel.gradient_support(model)
+    inside = torch.zeros(total, dtype=torch.bool)
+    for a, b in (segs or [(0, total)]):
+        inside[a:b] = True
+    g3 = torch.Generator().manual_seed(200 + rank)
+    flat3.copy_(torch.randn(total, generator=g3) * inside)
+    mine3 = flat3.clone()
+    parallel.allreduce_gradients(model)
+    parts = [torch.empty_like(mine3) for _ in range(world)]
+    dist.all_gather(parts, mine3)
+    ok_support = segs is not None and float(inside.float().mean()) < 0.9 and torch.allclose(flat3, sum(parts) / world, atol=1e-6)
     s = parallel.allreduce_scalar(torch.tensor(float(rank)))
-    q.put((rank, ok_shard, ok_grad, ok_flat, float(s)))
+    q.put((rank, ok_shard, ok_grad, ok_flat and ok_support, float(s)))
     dist.destroy_process_group()
 
 
