@@ -30,8 +30,8 @@ for rep in range(2):
 ws = model.last["ws"]
 ints = ws.bin_ints.cpu()
 nkeys = ws.binned_cfg[1]; nmax = max(ws.binned_cfg[0], ws.binned_cfg[1])
-hist = ints[:nkeys]
-choff = ints[3 * (nmax + 8): 3 * (nmax + 8) + nkeys + 1]
+hist = ws.hist_app.cpu()[:nkeys]            # (left as counted: the scan kernel reads it, the next forward zeroes it)
+choff = ints[2 * (nmax + 8): 2 * (nmax + 8) + nkeys + 1]
 print("app job: nkeys", nkeys, "entries*6", int(hist.sum()), "nonempty keys", int((hist > 0).sum()), "max bin", int(hist.max()),
       "work items", int(choff[nkeys]))
 names = ["search+setup", "zero/sync", "stage", "accumulate", "flush", "", "", "loop"]
