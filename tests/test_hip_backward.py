@@ -11,11 +11,15 @@ pytestmark = pytest.mark.gpu
 GRAD_RTOL = 2e-4     # relative to the largest |gradient| of the tensor (float atomics reorder the sums)
 
 
-@pytest.mark.parametrize("name", GRAD_CASES)
-def test_gradients_match_reference(recon, name):
+# every case through the binned scatter (the default); three also through the direct scatter (per-tap atomics with
+# line replicas), the path jobs beyond the sort's key limit fall back to
+@pytest.mark.parametrize("name,binned", [(n, True) for n in GRAD_CASES] +
+                         [("vm_cubic_train", False), ("vm_noncubic_relu", False), ("cp_train_mask", False)])
+def test_gradients_match_reference(recon, name, binned):
     c = Case(name)
     dev = "cuda:0"
     model = build_model(recon, c, dev)
+    model.binned_scatter = binned
     call = c.call
     torch.manual_seed(call["seed"])
     if call["ndc_ray"] and call["is_train"]:
