@@ -118,73 +118,6 @@ __device__ __forceinline__ void app_products(const TfShade& S, const float u[3],
     }
 }
 
-// VM appearance products with every tap of a round in flight before the first use.  The (axis, channel quad)
-// items of a sample are flattened (nq = sum n_comp / 4) and dealt round-robin to the `lps` lanes of the sample;
-// a round holds RI items = 6*RI 16-B loads per lane.  app_products() issues one quad (6 loads) at a time, which
-// makes the gather phase a chain of ~nq/lps memory latencies; this form pays one or two.
-// Requires every n_comp % 4 == 0 (the caller checks) — same arithmetic, same results as app_products().
-template <int RI>
-__device__ __forceinline__ void app_products_vm_batched(const TfShade& S, const float u[3], int sub, int lps, float* vrow) {
-    VmTaps t;
-    make_vm_taps(S.grid, u, t);
-    const int q0 = S.app.n_comp[0] >> 2, q1 = S.app.n_comp[1] >> 2, q2 = S.app.n_comp[2] >> 2, nq = q0 + q1 + q2;
-    for (int base = sub; base < nq; base += lps * RI) {
-        float4_t pa[RI], pb[RI], pc[RI], pd[RI], la[RI], lb[RI];
-#pragma unroll
-        for (int j = 0; j < RI; ++j) {
-            const int it = min(base + lps * j, nq - 1);          // past-the-end items repeat the last one (not stored)
-            const int ax = (it >= q0) + (it >= q0 + q1);
-            const int q = it - (ax == 0 ? 0 : (ax == 1 ? q0 : q0 + q1));
-            const int C = ax == 0 ? 4 * q0 : (ax == 1 ? 4 * q1 : 4 * q2);
-            const float* P = ax == 0 ? S.app.plane[0] : (ax == 1 ? S.app.plane[1] : S.app.plane[2]);
-            const float* Ln = ax == 0 ? S.app.line[0] : (ax == 1 ? S.app.line[1] : S.app.line[2]);
-            const int o00 = ax == 0 ? t.p[0].o00 : (ax == 1 ? t.p[1].o00 : t.p[2].o00);
-            const int o01 = ax == 0 ? t.p[0].o01 : (ax == 1 ? t.p[1].o01 : t.p[2].o01);
-            const int o10 = ax == 0 ? t.p[0].o10 : (ax == 1 ? t.p[1].o10 : t.p[2].o10);
-            const int o11 = ax == 0 ? t.p[0].o11 : (ax == 1 ? t.p[1].o11 : t.p[2].o11);
-            const int l0 = ax == 0 ? t.l[0].o0 : (ax == 1 ? t.l[1].o0 : t.l[2].o0);
-            const int l1 = ax == 0 ? t.l[0].o1 : (ax == 1 ? t.l[1].o1 : t.l[2].o1);
-            pa[j] = ld4(P + (size_t)o00 * C + q * 4);
-            pb[j] = ld4(P + (size_t)o01 * C + q * 4);
-            pc[j] = ld4(P + (size_t)o10 * C + q * 4);
-            pd[j] = ld4(P + (size_t)o11 * C + q * 4);
-            la[j] = ld4(Ln + (size_t)l0 * C + q * 4);
-            lb[j] = ld4(Ln + (size_t)l1 * C + q * 4);
-        }
-#pragma unroll
-        for (int j = 0; j < RI; ++j) {
-            const int it = base + lps * j;
-            if (it < nq) {
-                const int ax = (it >= q0) + (it >= q0 + q1);
-                const int q = it - (ax == 0 ? 0 : (ax == 1 ? q0 : q0 + q1));
-                const float w00 = ax == 0 ? t.p[0].w00 : (ax == 1 ? t.p[1].w00 : t.p[2].w00);
-                const float w01 = ax == 0 ? t.p[0].w01 : (ax == 1 ? t.p[1].w01 : t.p[2].w01);
-                const float w10 = ax == 0 ? t.p[0].w10 : (ax == 1 ? t.p[1].w10 : t.p[2].w10);
-                const float w11 = ax == 0 ? t.p[0].w11 : (ax == 1 ? t.p[1].w11 : t.p[2].w11);
-                const float w0 = ax == 0 ? t.l[0].w0 : (ax == 1 ? t.l[1].w0 : t.l[2].w0);
-                const float w1 = ax == 0 ? t.l[0].w1 : (ax == 1 ? t.l[1].w1 : t.l[2].w1);
-                const float* mk = ax == 0 ? S.app.mask[0] : (ax == 1 ? S.app.mask[1] : S.app.mask[2]);
-                float4_t p, l;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {   // the exact expressions of bilerp4 / lerp4
-                    p[k] = fmaf(pd[j][k], w11, fmaf(pc[j][k], w10, fmaf(pb[j][k], w01, pa[j][k] * w00)));
-                    l[k] = fmaf(lb[j][k], w1, la[j][k] * w0);
-                }
-                if (mk) {
-                    const float4_t m = ld4(mk + q * 4);
-                    p *= m;
-                    l *= m;
-                }
-                *reinterpret_cast<float4_t*>(vrow + it * 4) = p * l;   // coff + 4q == 4*it: the axes are laid out back to back
-            }
-        }
-    }
-}
-
-__device__ __forceinline__ bool vm_quads_ok(const TfShade& S) {
-    return S.model == TF_MODEL_VM && ((S.app.n_comp[0] | S.app.n_comp[1] | S.app.n_comp[2]) & 3) == 0;
-}
-
 // sin and cos of the positional-encoding arguments (mlp.py:8-13).  Cody-Waite reduction by pi/2 in three
 // parts + the Cephes single-precision minimax polynomials: <= ~1.5 ulp for |x| < 8192 at ~30 VALU
 // instructions for the pair (the library sincosf carries a Payne-Hanek path and costs several times that;
