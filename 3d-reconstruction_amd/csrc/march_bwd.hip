@@ -141,7 +141,12 @@ __global__ __launch_bounds__(64) void march_backward_kernel(const TfField F, con
             df = ds * e * density_act_grad(F, f);          // d alpha / d f
         }
         const float incl = wave_scan_add(wdw);     // lanes are in reverse sample order -> inclusive suffix
-        const float suffix = carry + (incl - wdw); // strictly later samples
+        // strictly later samples: the EXCLUSIVE scan value (the neighbour's inclusive one).  `incl - wdw` loses the
+        // suffix to rounding when a nearly opaque sample's own term dwarfs everything behind it (saturated alpha:
+        // a 0.7 % error in dL/dsigma, found by the random-configuration test with the ReLU activation).
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 0.f;
+        const float suffix = carry + excl;
         carry += __shfl(incl, 63, 64);
         if (act) {
             const float dalpha = Tk * dw - suffix / t;
