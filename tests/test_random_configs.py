@@ -54,19 +54,24 @@ def _build(recon, seed):
         model.alphaMask = None
     R_ = 700 + 37 * (seed % 5)
     rays = (S.llff_ndc_rays(R_, seed=seed) if ndc else S.blender_rays(1)[seed::997][:R_]).to(DEV).contiguous()
-    return model, rays, ndc, args
+    mask = None
+    if seed % 3 == 0:     # frequency / component masks of the training loop (utils.get_free_mask, train.py:303-318)
+        mask = recon.get_free_mask(pos_bl=model.pos_bit_length, view_bl=model.view_bit_length, fea_bl=model.fea_bit_length,
+                                   den_bl=model.density_n_comp, app_bl=model.app_n_comp, step=37 * (seed % 7) + 5,
+                                   total_step=300, device=DEV)
+    return model, rays, ndc, args, mask
 
 
-@pytest.mark.parametrize("seed", list(range(12)))
+@pytest.mark.parametrize("seed", list(range(40)))
 def test_random_configuration(recon, seed):
-    model, rays, ndc, args = _build(recon, seed)
+    model, rays, ndc, args, mask = _build(recon, seed)
     N = min(int(model.nSamples), 400)
     white = not ndc
     model._debug_masks = True
     with torch.no_grad():
-        rgb, depth, nvalid = model(rays, None, white_bg=white, is_train=False, ndc_ray=ndc, N_samples=N)
+        rgb, depth, nvalid = model(rays, mask, white_bg=white, is_train=False, ndc_ray=ndc, N_samples=N)
         cfg, params = oracle_of(model, DEV)
-        o_rgb, o_depth, o_n, mid = R.render_rays(cfg, params, rays, None, white_bg=white, is_train=False, ndc_ray=ndc,
+        o_rgb, o_depth, o_n, mid = R.render_rays(cfg, params, rays, mask, white_bg=white, is_train=False, ndc_ray=ndc,
                                                  n_samples=N, keep=True)
     ws, R_ = model.last["ws"], rays.shape[0]
     assert np.array_equal(bits_to_mask(ws.dbg_bbox, R_, N), mid["bbox_valid"].cpu().numpy()), "bbox mask"
@@ -85,14 +90,14 @@ def test_random_configuration(recon, seed):
     torch.manual_seed(100 + seed)
     if ndc:
         model._jitter_override = torch.rand(1, N)
-    out, _, _ = model(rays, None, white_bg=True, is_train=True, ndc_ray=ndc, N_samples=N)
+    out, _, _ = model(rays, mask, white_bg=True, is_train=True, ndc_ray=ndc, N_samples=N)
     loss = torch.mean((out - target) ** 2)
     loss.backward()
     for p in params.values():
         p.requires_grad_(True)
     torch.manual_seed(100 + seed)
     jit = torch.rand(1, N).to(DEV) if ndc else None
-    o_out, _, _ = R.render_rays(cfg, params, rays, None, white_bg=True, is_train=True, ndc_ray=ndc, n_samples=N, jitter=jit)
+    o_out, _, _ = R.render_rays(cfg, params, rays, mask, white_bg=True, is_train=True, ndc_ray=ndc, n_samples=N, jitter=jit)
     o_loss = torch.mean((o_out - target) ** 2)
     o_loss.backward()
     assert abs(loss.item() - o_loss.item()) <= 2e-5 * abs(o_loss.item())
@@ -113,5 +118,5 @@ def test_random_configuration(recon, seed):
         worst = max(worst, rel)
         assert rel <= 2e-3 or len(flips) > 0, (k, rel)
     print(f"seed {seed}: {type(model).__name__} {args['shadingMode']} C={args['density_n_comp']}/{args['app_n_comp']} "
-          f"grid {model.gridSize.tolist()} ndc={ndc} mask={model.alphaMask is not None} shaded/ray={shaded / R_:.1f} "
+          f"grid {model.gridSize.tolist()} ndc={ndc} alpha={model.alphaMask is not None} free_mask={mask is not None} shaded/ray={shaded / R_:.1f} "
           f"flips={len(flips)} worst grad L2 rel={worst:.1e}")
