@@ -157,3 +157,47 @@ def test_tiny_grids_and_sample_counts(recon, grid, N):
         if og is None or float(og.abs().max()) < 1e-5 * top:
             continue
         assert (p.grad - og).norm().item() <= 5e-3 * og.norm().item(), k
+
+
+@pytest.mark.parametrize("seed", [0, 1, 4, 7, 11, 13])
+def test_lifecycle_kernels_on_random_configurations(recon, seed):
+    """tf_alpha_points (compute_alpha), tf_sample_alpha_points (AlphaGridMask.sample_alpha) and tf_filter_rays
+    (filtering_rays) against the oracle's pieces on random fields, points inside and outside the boxes."""
+    model, rays, ndc, args, _ = _build(recon, seed)
+    if model.alphaMask is None:
+        from recon_amd import synthetic as S
+        S.make_trained_like(model, recon.AlphaGridMask, mask_res=29, radius=0.85)
+    cfg, params = oracle_of(model, DEV)
+    g = torch.Generator().manual_seed(seed)
+    lo, hi = model.aabb[0].cpu(), model.aabb[1].cpu()
+    pts = (lo + (hi - lo) * (torch.rand(5000, 3, generator=g) * 1.3 - 0.15)).to(DEV)     # 15 % margin outside the box
+    with torch.no_grad():
+        # sample_alpha: trilinear look-up of the mask volume, zero outside
+        got = model.alphaMask.sample_alpha(pts)
+        ref = R.alpha_lookup(cfg, pts)
+        np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        # compute_alpha: mask test, density, activation, 1 - exp(-sigma * length)   (tensorBase.py:298-318)
+        length = float(model.stepSize)
+        got = model.compute_alpha(pts, None, length)
+        keep = ref > 0
+        sigma = torch.zeros(pts.shape[0], device=DEV)
+        if keep.any():
+            sigma[keep] = R.feature2density(cfg, R.density_feature(cfg, params, R.normalize_coord(cfg, pts[keep])))
+        want = 1 - torch.exp(-sigma * length)
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    if ndc:
+        return
+    # filtering_rays (tensorBase.py:259-288): bbox slab test, and "any of N eval samples hits the mask"
+    idx = torch.arange(rays.shape[0]).float()[:, None]
+    frays = rays.cpu()
+    _, kept = model.filtering_rays(frays, idx, bbox_only=True)
+    o, d = rays[:, :3], rays[:, 3:6]
+    vec = torch.where(d == 0, torch.full_like(d, 1e-6), d)
+    ra, rb = (model.aabb[1] - o) / vec, (model.aabb[0] - o) / vec
+    want = torch.maximum(ra, rb).amin(-1) > torch.minimum(ra, rb).amax(-1)
+    assert kept.view(-1).long().tolist() == torch.nonzero(want.cpu()).view(-1).tolist()
+    _, kept = model.filtering_rays(frays, idx, N_samples=48)
+    with torch.no_grad():
+        p, _, _ = R.sample_ray(cfg, o, d, False, 48)
+        want = (R.alpha_lookup(cfg, p.reshape(-1, 3)).view(p.shape[:-1]) > 0).any(-1)
+    assert kept.view(-1).long().tolist() == torch.nonzero(want.cpu()).view(-1).tolist()
