@@ -278,7 +278,7 @@ __host__ __device__ inline int lane_group(int c) { return c <= 16 ? 16 : (c <= 3
 //          accumulation block (LDS float atomics measured ~100 cycles per wave-instruction, a plain RMW is 3 short
 //          LDS ops; lanes of one instruction never collide and the LDS pipe is in order).  No global access.
 //   The four private blocks are summed when the work item is flushed.
-__global__ __launch_bounds__(256, 5) void bin_scatter_kernel(const TfBinJob J, const KeyMap K, int ER, int cmax) {
+__global__ __launch_bounds__(256, 4) void bin_scatter_kernel(const TfBinJob J, const KeyMap K, int ER, int cmax) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wstride = ER * (cmax + 8);
     const int total = J.chunk_off[K.nkeys];
@@ -325,16 +325,33 @@ __global__ __launch_bounds__(256, 5) void bin_scatter_kernel(const TfBinJob J, c
         const bool vec = (C & 3) == 0 && (CF & 3) == 0 && (coff & 3) == 0 && (J.grad_ld & 3) == 0;
         const int rounds = (end - beg + 4 * ER - 1) / (4 * ER);
         TF_MARK(0);
+        // The entry index is fetched two rounds ahead and its coordinates one round ahead, so that a round's stage
+        // depends on ONE level of random global loads (factor taps + gradient piece) instead of three in a chain
+        // (index -> coordinates -> taps).
+        const int LPE = 64 / ER, ent = lane / LPE, sub = lane - ent * LPE;
+        auto idx_of = [&](int rd) {
+            const int b = beg + (rd * 4 + wave) * ER + ent;
+            return (rd < rounds && b < end) ? J.binned[b] : -1;
+        };
+        int e_cur = idx_of(0), e_nxt = idx_of(1);
+        float u_cur[3] = {0.f, 0.f, 0.f};
+        if (e_cur >= 0) {
+            u_cur[0] = J.xyz[(size_t)e_cur * 3]; u_cur[1] = J.xyz[(size_t)e_cur * 3 + 1]; u_cur[2] = J.xyz[(size_t)e_cur * 3 + 2];
+        }
         for (int rd = 0; rd < rounds; ++rd) {
             const int base = beg + (rd * 4 + wave) * ER;
             const int nk = max(0, min(ER, end - base));
+            const int e_far = idx_of(rd + 2);
+            float u_nxt[3] = {0.f, 0.f, 0.f};
+            if (e_nxt >= 0) {
+                u_nxt[0] = J.xyz[(size_t)e_nxt * 3]; u_nxt[1] = J.xyz[(size_t)e_nxt * 3 + 1]; u_nxt[2] = J.xyz[(size_t)e_nxt * 3 + 2];
+            }
             __syncthreads();                         // blk zeroed / previous round's staging consumed
             TF_MARK(1);
             // ---------------- stage: LPE = 64 / ER lanes per entry, lane `sub` takes channel quads sub, sub+LPE, ...
-            const int LPE = 64 / ER, ent = lane / LPE, sub = lane - ent * LPE;
             if (ent < nk) {
-                const int e = J.binned[base + ent];
-                const float u[3] = {J.xyz[(size_t)e * 3], J.xyz[(size_t)e * 3 + 1], J.xyz[(size_t)e * 3 + 2]};
+                const int e = e_cur;
+                const float u[3] = {u_cur[0], u_cur[1], u_cur[2]};
                 const Tap2 tp = make_tap2(u[mat0(i)], u[mat1(i)], W, Hh);
                 const Tap1 tl = make_tap1(u[vecm(i)], Gl);
                 float* mrow = meta + ent * 8;
@@ -407,6 +424,9 @@ __global__ __launch_bounds__(256, 5) void bin_scatter_kernel(const TfBinJob J, c
                     blk[a] = fmaf(pre[k * C + c], mrow[wsel], blk[a]);
                 }
             }
+            e_cur = e_nxt;
+            e_nxt = e_far;
+            u_cur[0] = u_nxt[0]; u_cur[1] = u_nxt[1]; u_cur[2] = u_nxt[2];
         }
         __syncthreads();
         TF_MARK(3);
