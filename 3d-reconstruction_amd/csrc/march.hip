@@ -257,14 +257,15 @@ __global__ __launch_bounds__(256) void pack_matrices_kernel(const TfPackJob J) {
 
 // loss = mean((a - b)^2) over n floats and grad = d loss / d a = 2 (a - b) / n, one workgroup (n is 3 x rays)
 __global__ __launch_bounds__(1024) void mse_grad_kernel(const float* __restrict__ a, const float* __restrict__ b, int n,
-                                                        float* __restrict__ loss, float* __restrict__ grad) {
+                                                        float grad_scale, float* __restrict__ loss,
+                                                        float* __restrict__ grad) {
     __shared__ float red[16];
     const float inv = 1.f / (float)n;
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += 1024) {
         const float d = a[i] - b[i];
         s = fmaf(d, d, s);
-        grad[i] = 2.f * d * inv;
+        grad[i] = 2.f * d * inv * grad_scale;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -350,9 +351,9 @@ int tf_pack_matrices(const TfPackJob* job, tf_stream_t stream) {
     return TF_CHECK_LAUNCH();
 }
 
-int tf_mse_grad(const float* a, const float* b, int n, float* loss, float* grad, tf_stream_t stream) {
+int tf_mse_grad(const float* a, const float* b, int n, float grad_scale, float* loss, float* grad, tf_stream_t stream) {
     if (n <= 0) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(mse_grad_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, b, n, loss, grad);
+    hipLaunchKernelGGL(mse_grad_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, b, n, grad_scale, loss, grad);
     return TF_CHECK_LAUNCH();
 }
 

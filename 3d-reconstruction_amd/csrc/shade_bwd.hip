@@ -66,19 +66,35 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[NA][NBT]) {
 
 struct BwdLds {
     int sv, sx, sh, sf;
-    int offV, offX, offH1, offH2, offDo, offInfo, offPre, total;
+    int offV, offX, offH1, offH2, offF, offDo, offInfo, offPre, total;
+    int rg;      // 1: V does not fit next to X, H1, H2 -> it shares the H1 | H2 space and is gathered a second time
 };
 __host__ __device__ inline BwdLds bwd_lds(const TfShade& S) {
     BwdLds L;
     L.sv = kpad16(S.n_app_total) + 4;
     L.sx = kpad16(S.in_c) + 4;
     L.sh = S.feature_c + 4;
-    L.sf = 36;                       // feat copy / dfeat rows (<= 32 used), carved from the H2 region
+    L.sf = 36;                       // feat copy / dfeat rows (<= 32 used)
+    L.rg = 0;
     L.offV = 0;
     L.offX = L.offV + M * L.sv;
     L.offH1 = L.offX + M * L.sx;
     L.offH2 = L.offH1 + M * L.sh;
+    L.offF = L.offH2;                // carved from the H2 region, which is free once dZ1 exists
     L.offDo = L.offH2 + M * L.sh;
+    if ((size_t)(L.offDo + M * 12 + 80) * sizeof(float) > 160 * 1024) {
+        // Wide appearance bases (e.g. TensorCP [96]/[288] at featureC 128): V is only needed before the MLP (basis ->
+        // feat) and after it (dB, dV), so it takes the H1 | H2 space (plus what it needs beyond) and the kernel
+        // gathers it again once dX is done; feat copy / dfeat rows move out of its way.
+        L.rg = 1;
+        L.offX = 0;
+        L.offH1 = L.offX + M * L.sx;
+        L.offH2 = L.offH1 + M * L.sh;
+        L.offV = L.offH1;
+        const int end_v = L.offV + M * L.sv, end_h = L.offH2 + M * L.sh;
+        L.offF = end_v > end_h ? end_v : end_h;
+        L.offDo = L.offF + 2 * M * L.sf;
+    }
     L.offInfo = L.offDo + M * 4;
     L.offPre = L.offInfo + M * 8;
     L.total = L.offPre + 80;
@@ -95,7 +111,7 @@ __host__ __device__ inline size_t wslab_floats(const TfShade& S) {
 // layer's k tiles kept in registers.  512 threads = 8 waves = 2 per SIMD (256 registers each, no scratch:
 // kernels that spill cannot be replayed from a hipGraph on this stack).
 // Wave w: feature tile ft = w % FT, sample group sg = w / FT (SG = 8/FT groups of NSW = 4/SG sample tiles).
-template <int FT, int NB, int KT1>
+template <int FT, int NB, int KT1, bool RG>
 __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S, const TileSrc src,
                                                                  const float* __restrict__ grad_rgb,
                                                                  const TfShadeGrads G) {
@@ -106,8 +122,8 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
     float* X = lds + L.offX;
     float* H1 = lds + L.offH1;
     float* H2 = lds + L.offH2;
-    float* Fs = H2;                       // feat copy   [64][sf]   (H2 region is free once dZ1 exists)
-    float* Fd = H2 + M * L.sf;            // dfeat       [64][sf]
+    float* Fs = lds + L.offF;             // feat copy   [64][sf]
+    float* Fd = Fs + M * L.sf;            // dfeat       [64][sf]
     float* dO = lds + L.offDo;            // [64][4]
     int* iray = reinterpret_cast<int*>(lds + L.offInfo);
     float* ixyz = lds + L.offInfo + M;
@@ -410,6 +426,13 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         }
         lds_barrier();
         TF_MARK(5);
+        if (RG) {   // V again (its space held H1 / H2 meanwhile); lands while the PE derivative below computes
+            const int smp = wave * 8 + (lane >> 3), sub = lane & 7;
+            float u[3] = {ixyz[smp * 3], ixyz[smp * 3 + 1], ixyz[smp * 3 + 2]};
+            float* vrow = V + smp * L.sv;
+            app_products(S, u, sub, vrow, 8);
+            for (int c = S.n_app_total + sub; c < kpB; c += 8) vrow[c] = 0.f;
+        }
         {   // dfeat = dX[:, :D] + PE'(feat): d/dx [sin(x 2^k) m_s] = cos(.) 2^k m_s,  d/dx [cos(.) m_c] = -sin(.) 2^k m_c
             for (int it = tid; it < M * 16 * NB; it += NT) {
                 const int smp = it / (16 * NB), d = it % (16 * NB);
@@ -603,18 +626,19 @@ __global__ __launch_bounds__(256) void app_direct_scatter_kernel(const TfShade S
 typedef void (*bwd_fn_t)(const TfShade, const TileSrc, const float*, const TfShadeGrads);
 
 template <int FT, int NB>
-bwd_fn_t pick_kt(int kt1) {
-    if (kt1 <= 4) return shade_backward_kernel<FT, NB, 4>;
-    if (kt1 <= 8) return shade_backward_kernel<FT, NB, 8>;
-    if (kt1 <= 12) return shade_backward_kernel<FT, NB, 12>;
+bwd_fn_t pick_kt(int kt1, bool rg) {
+    if (kt1 <= 4) return rg ? shade_backward_kernel<FT, NB, 4, true> : shade_backward_kernel<FT, NB, 4, false>;
+    if (kt1 <= 8) return rg ? shade_backward_kernel<FT, NB, 8, true> : shade_backward_kernel<FT, NB, 8, false>;
+    if (kt1 <= 12) return rg ? shade_backward_kernel<FT, NB, 12, true> : shade_backward_kernel<FT, NB, 12, false>;
     return nullptr;
 }
 
 bwd_fn_t pick_bwd(const TfShade& S) {
     const int nb = (S.app_dim + 15) / 16, kt1 = kpad16(S.in_c) / 16;
     if (S.head != TF_HEAD_MLP || nb > 2 || kpad16(S.n_app_total) / 16 > 24) return nullptr;
-    if (S.feature_c == 64) return nb == 1 ? pick_kt<4, 1>(kt1) : pick_kt<4, 2>(kt1);
-    if (S.feature_c == 128) return nb == 1 ? pick_kt<8, 1>(kt1) : pick_kt<8, 2>(kt1);
+    const bool rg = bwd_lds(S).rg != 0;
+    if (S.feature_c == 64) return nb == 1 ? pick_kt<4, 1>(kt1, rg) : pick_kt<4, 2>(kt1, rg);
+    if (S.feature_c == 128) return nb == 1 ? pick_kt<8, 1>(kt1, rg) : pick_kt<8, 2>(kt1, rg);
     return nullptr;
 }
 

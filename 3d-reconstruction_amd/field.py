@@ -560,7 +560,7 @@ class TensorBase(nn.Module):
                     raise H.HipError(
                         f"training is not supported for this shading head: featureC={self.featureC} (64 / 128), "
                         f"app_dim={self.app_dim} (<= 32), MLP input {sh.in_c} (<= 192), sum(app_n_comp)="
-                        f"{self._n_app_total()} (the 64-sample tile must fit 160 KB of LDS: <= 176 at featureC 128)")
+                        f"{self._n_app_total()} (<= 384, and the 64-sample tile must fit the 160 KB of LDS)")
                 wslab = int(H.lib().tf_shade_backward_wslab_floats(C.byref(sh))) if sh.head == H.HEAD_MLP else 64
                 extra = (self._n_app_total(), wslab)
             ws = _Workspace(R, N, dev, save_valid, self._debug_masks, binned, extra)

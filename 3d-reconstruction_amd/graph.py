@@ -13,7 +13,10 @@ step — with the one gradient all-reduce (`parallel.allreduce_gradients`, RCCL)
 replays on the same stream, so no collective is ever inside a capture.
 
 Restrictions (else use the eager path): fixed batch size / N_samples, `white_bg=True` (the random background
-draw of tensorBase.py:380 is a host decision per step)."""
+draw of tensorBase.py:380 is a host decision per step).  Results of EARLIER eager training forwards of the same
+model (`rgb`, the loss) must not be alive when the step is captured: they keep autograd's AccumulateGrad nodes bound
+to the stream they ran on, the capture would record a dependency on that stream and HIP fails in
+`hipStreamEndCapture` (torch warns "AccumulateGrad node's stream does not match")."""
 import ctypes as C
 
 import torch
@@ -31,6 +34,9 @@ class GraphedTrainStep:
         self.split = (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) if split is None \
             else bool(split)
         self.graph_opt = None
+        # data parallel: d loss / d rgb is pre-divided by the world size and the ranks' gradients are summed, which
+        # equals averaging them without a second pass over the gradient buffer (1 / 2^k scales exactly)
+        self._world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         dev = next(model.parameters()).device
         self.rays = torch.zeros(batch, 6, device=dev)
         self.target = torch.zeros(batch, 3, device=dev)
@@ -52,7 +58,8 @@ class GraphedTrainStep:
         finally:
             model.count_samples = keep
         # loss = mean((rgb - target)^2) (train.py:334) and d loss / d rgb in one launch instead of ~8 torch kernels
-        H.check(H.lib().tf_mse_grad(rgb.data_ptr(), self.target.data_ptr(), rgb.numel(), self.loss.data_ptr(),
+        H.check(H.lib().tf_mse_grad(rgb.data_ptr(), self.target.data_ptr(), rgb.numel(),
+                                    1.0 / self._world if self.split else 1.0, self.loss.data_ptr(),
                                     self._grad_rgb.data_ptr(), _stream()), "tf_mse_grad")
         self.opt.zero_grad(set_to_none=True)
         rgb.backward(self._grad_rgb)
@@ -60,7 +67,7 @@ class GraphedTrainStep:
     def _body(self):
         self._fwd_bwd()
         if self.split:
-            parallel.allreduce_gradients(self.model)
+            parallel.allreduce_gradients(self.model, average=False)
         self.opt.step()
 
     def _stage(self, rays, target, ids=None):
@@ -81,7 +88,7 @@ class GraphedTrainStep:
         if self.graph is not None:
             self.graph.replay()
             if self.split:
-                parallel.allreduce_gradients(self.model)      # on model.grad_flat: a static buffer of the graph's pool
+                parallel.allreduce_gradients(self.model, average=False)      # on model.grad_flat: a static buffer of the graph's pool
                 self.graph_opt.replay()
             return self.loss
         self.model.static_jitter = self.jitter
@@ -101,13 +108,15 @@ class GraphedTrainStep:
             self.graph = g
             g.replay()                                            # capture only records; run this step now
             return self.loss
-        with torch.cuda.graph(g, stream=self._side):
+        # thread-local capture mode: the process group's helper threads (RCCL proxy / watchdog, gloo workers) may
+        # make HIP calls of their own while this thread captures; they never touch the captured stream
+        with torch.cuda.graph(g, stream=self._side, capture_error_mode="thread_local"):
             self._fwd_bwd()
         g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2, stream=self._side, pool=g.pool()):
+        with torch.cuda.graph(g2, stream=self._side, pool=g.pool(), capture_error_mode="thread_local"):
             self.opt.step()
         self.graph, self.graph_opt = g, g2
         g.replay()
-        parallel.allreduce_gradients(self.model)
+        parallel.allreduce_gradients(self.model, average=False)
         g2.replay()
         return self.loss

@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--views", type=int, default=3)
     ap.add_argument("--no-baselines", action="store_true", help="skip the CPU / ROCm-eager baseline legs")
     ap.add_argument("--no-graph", action="store_true", help="drive the train step eagerly instead of replaying a hipGraph")
+    ap.add_argument("--host-inputs", action="store_true",
+                    help="rays / targets stay in (pinned) host memory; every step gathers its batch on the CPU and copies "
+                         "it over PCIe like train.py:297-298 (diagnostic: the PCIe-inclusive rate, never the headline)")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the one-launch tf_adam_step")
     return ap.parse_args()
 
@@ -222,6 +225,23 @@ def main():
     def graph_step(i):
         return graphed.step(rays, targets, parallel.shard_ids(perm[i], rank, world))
 
+    if args.host_inputs:
+        assert use_graph, "--host-inputs is implemented for the graphed train step"
+        rays_h, targets_h, perm_h = rays.cpu().pin_memory(), targets.cpu().pin_memory(), perm.cpu()
+        stage_r = [torch.empty(B, 6).pin_memory() for _ in range(2)]      # double-buffered: the copy of step i may
+        stage_t = [torch.empty(B, 3).pin_memory() for _ in range(2)]      # still be in flight while step i+1 gathers
+        stage_ev = [torch.cuda.Event(), torch.cuda.Event()]
+
+        def graph_step(i):      # noqa: F811  (train mode, graphed)
+            ids = parallel.shard_ids(perm_h[i], rank, world)
+            b = i & 1
+            stage_ev[b].synchronize()
+            torch.index_select(rays_h, 0, ids, out=stage_r[b])
+            torch.index_select(targets_h, 0, ids, out=stage_t[b])
+            out = graphed.step(stage_r[b], stage_t[b])
+            stage_ev[b].record()
+            return out
+
     step = (graph_step if use_graph else train_step) if args.mode == "train" else eval_step
     # the scene set-up leaves ~10^6 long-lived Python objects behind; without this the cyclic collector re-walks
     # them every few steps of the eager paths (measured: 3 ms pauses on a 0.2 ms step)
@@ -312,6 +332,7 @@ def main():
                        "launch": ("hipGraph replay" if world == 1 else "2 hipGraph replays around one RCCL all-reduce")
                                  if use_graph else "eager",
                        "optimizer": "torch.optim.Adam(fused)" if args.torch_adam else "Adam, one launch (tf_adam_step)",
+                       "inputs": "host, gathered on the CPU + H2D per step" if args.host_inputs else "resident in HBM",
                        "eager_ms_per_step": eager_ms, "host_issue_ms_per_step": host_issue / k * 1e3},
             "roofline": roof,
             "kernels": {n: {"avg_ms": round(v["avg_ms"], 5), "GBps": round(v["GBps"], 1),

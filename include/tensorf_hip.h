@@ -169,8 +169,10 @@ typedef struct TfPackJob {
 int tf_pack_matrices(const TfPackJob* job, tf_stream_t stream);
 
 /* The photometric loss of train.py:334 and its gradient in one launch: *loss = mean((a - b)^2) over n floats,
- * grad[i] = 2 (a[i] - b[i]) / n.  (Used by the hipGraph-captured step; eager callers keep their torch expression.) */
-int tf_mse_grad(const float* a, const float* b, int n, float* loss, float* grad, tf_stream_t stream);
+ * grad[i] = grad_scale * 2 (a[i] - b[i]) / n.  grad_scale is 1 for a single process and 1 / world_size under data
+ * parallelism, where the ranks' gradients are then SUMMED (no separate averaging pass over the gradient buffer).
+ * (Used by the hipGraph-captured step; eager callers keep their torch expression.) */
+int tf_mse_grad(const float* a, const float* b, int n, float grad_scale, float* loss, float* grad, tf_stream_t stream);
 
 /* sample_ray / sample_ray_ndc + bbox test + AlphaGridMask test + compute_densityfeature +
  * feature2density + raw2alpha + app_mask + acc/depth reductions:
@@ -217,7 +219,8 @@ typedef struct TfShadeGrads {
 } TfShadeGrads;
 size_t tf_shade_backward_wslab_floats(const TfShade* shade);
 /* 1 when tf_shade_backward supports this head (MLP, feature_c 64 / 128, app_dim <= 32, in_c <= 192, and the
- * 64-sample tile of V, X, H1, H2 fits the 160 KB of LDS: sum of appearance components <= 176 at feature_c 128). */
+ * 64-sample tile fits the 160 KB of LDS; when V, X, H1, H2 do not fit side by side — more than 176 appearance
+ * components at feature_c 128 — V shares the hidden layers' space and is gathered twice: up to 384 components). */
 int tf_shade_backward_supported(const TfShade* shade);
 int tf_shade_backward(const TfShade* shade, const float* rays, int ndc, const int* counters, int seg_cap,
                       const int* app_ray, const float* app_xyz, const float* grad_rgb, const TfShadeGrads* grads,

@@ -150,5 +150,16 @@ def test_gradient_support_bounds_the_real_gradients(recon, scene):
     frac = float(inside.float().mean())
     assert float(flat.abs().sum()) > 0 and frac < 0.9
     assert float(flat[~inside].abs().max()) == 0.0, "a gradient entry outside the exchanged support is non-zero"
+    # the cell-level support (what allreduce_gradients exchanges by default): tighter, and still a superset
+    rows = parallel.gradient_support_rows(model)
+    assert rows is not None
+    w, idx = rows
+    in_rows = torch.zeros(flat.numel() // w, dtype=torch.bool, device=DEV)
+    in_rows[idx] = True
+    assert float(flat.view(-1, w)[~in_rows].abs().max()) == 0.0, "a gradient entry outside the exchanged cells is non-zero"
+    cell_frac = idx.numel() * w / flat.numel()
+    assert cell_frac < frac
+    live = float((flat.view(-1, w)[in_rows].abs().amax(1) > 0).float().mean())
+    print(scene, f"cells = {cell_frac:.2%} of the gradient buffer ({live:.0%} of them non-zero in this one step)")
     # tightness: the outermost exchanged rows of the largest plane are within a few rows of real data
     print(scene, f"support = {frac:.2%} of the gradient buffer, {len(segs)} segments")

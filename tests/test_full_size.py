@@ -38,10 +38,10 @@ def _scene(recon, name):
     elif name.startswith("C3_cp300"):
         aabb = torch.tensor(S.LEGO_AABB, device=DEV)
         head = "SH" if name.endswith("sh") else "MLP_Fea"
-        # the SH case is BASELINE config 3 ([96]/[288], inference only: the reference cannot train that head
-        # either); the trainable CP case uses the widest appearance decomposition the shading backward holds in
-        # LDS (sum of app components <= 176 at featureC = 128)
-        args = S.lego_args(head, density_n_comp=(96,), app_n_comp=(288,) if head == "SH" else (176,))
+        # BASELINE config 3 ([96]/[288], configs/lego.txt:80-83): with the SH head inference only (the reference
+        # cannot train that head either); with MLP_Fea also trained — at 288 components the backward's tile does not
+        # fit LDS in one piece, which exercises its gather-V-twice layout
+        args = S.lego_args(head, density_n_comp=(96,), app_n_comp=(288,))
         model = recon.TensorCP(args, aabb, recon.N_to_reso(300 ** 3, aabb), near_far=S.LEGO_NEAR_FAR, device=DEV)
         rays = S.blender_rays(1)
     elif name == "C4_ndc":

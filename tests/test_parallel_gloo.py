@@ -91,10 +91,27 @@ def _worker(rank, world, port, q):
     g3 = torch.Generator().manual_seed(200 + rank)
     flat3.copy_(torch.randn(total, generator=g3) * inside)
     mine3 = flat3.clone()
-    parallel.allreduce_gradients(model)
+    parallel.allreduce_gradients(model, use_support="blocks")
     parts = [torch.empty_like(mine3) for _ in range(world)]
     dist.all_gather(parts, mine3)
     ok_support = segs is not None and float(inside.float().mean()) < 0.9 and torch.allclose(flat3, sum(parts) / world, atol=1e-6)
+    # 5. the cell-level support (the default): a subset of the row blocks, same result where the gradients live
+    rows = parallel.gradient_support_rows(model)
+    ok_cells = rows is not None
+    if ok_cells:
+        w, idx = rows
+        in_rows = torch.zeros(total // w, dtype=torch.bool)
+        in_rows[idx] = True
+        in_cells = in_rows[:, None].expand(-1, w).reshape(-1)
+        p0, p1 = offs["density_plane.0"], offs["app_plane.2"] + model.app_plane[2].numel()
+        ok_cells = bool((in_cells <= inside)[p0:p1].all()) and float(in_cells.float().mean()) < 0.7 * float(inside.float().mean())
+        flat3.copy_(torch.randn(total, generator=g3) * in_cells)
+        mine5 = flat3.clone()
+        parallel.allreduce_gradients(model, average=False)
+        parts = [torch.empty_like(mine5) for _ in range(world)]
+        dist.all_gather(parts, mine5)
+        ok_cells = ok_cells and torch.allclose(flat3, sum(parts), atol=1e-6)
+    ok_support = ok_support and ok_cells
     s = parallel.allreduce_scalar(torch.tensor(float(rank)))
     q.put((rank, ok_shard, ok_grad, ok_flat and ok_support, float(s)))
     dist.destroy_process_group()

@@ -1,0 +1,115 @@
+"""GPU, world_size 2: the data-parallel train step as the driver's N > 1 bench runs it — real HIP gradients, the
+cell-level support-limited exchange, the split hipGraph step.  Both ranks share cuda:0, so the collective goes over
+gloo (RCCL refuses two ranks on one device); everything else is the code path of `bench.py --gpus N`."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _scene(recon, dev):
+    from recon_amd import synthetic as S
+    torch.manual_seed(0)
+    aabb = torch.tensor(S.LEGO_AABB, device=dev)
+    args = S.lego_args(density_n_comp=(8, 8, 8), app_n_comp=(16, 16, 16))
+    model = recon.TensorVMSplit(args, aabb, [72, 64, 80], S.LEGO_NEAR_FAR, dev)
+    S.make_trained_like(model, recon.AlphaGridMask, mask_res=40, radius=0.6)
+    allrays = S.blender_rays(1)
+    rays = allrays[torch.randperm(allrays.shape[0], generator=torch.Generator().manual_seed(2))[:4096]].to(dev).contiguous()
+    target = torch.rand(rays.shape[0], 3, generator=torch.Generator().manual_seed(9)).to(dev)
+    return model, rays, target
+
+
+def _worker(rank, world, port, q):
+    import faulthandler
+    import sys
+    faulthandler.enable()
+    faulthandler.dump_traceback_later(150, exit=True)     # a rank that hangs reports where, instead of the peer timing out
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import recon_amd as recon
+    from recon_amd import parallel
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dev = "cuda:0"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {"rank": rank}
+    try:
+        model, rays, target = _scene(recon, dev)
+        ids = parallel.shard_ids(torch.arange(2048, device=dev), rank, world)
+        N = 200
+        # 1. eager: exchanged gradient == mean of the ranks' local gradients, over the WHOLE buffer (nothing outside
+        #    the exchanged cells may have been non-zero anywhere)
+        print(f"[rank {rank}] scene ready", flush=True)
+        torch.manual_seed(10 + rank)
+        rgb, _, _ = model(rays[ids], None, white_bg=True, is_train=True, N_samples=N)
+        torch.mean((rgb - target[ids]) ** 2).backward()
+        local = model.grad_flat.clone()
+        rows = parallel.gradient_support_rows(model)
+        out["cells"] = None if rows is None else rows[1].numel() * rows[0] / local.numel()
+        parallel.allreduce_gradients(model)
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(parts, local)
+        expect = sum(parts) / world
+        out["exchange_err"] = float((model.grad_flat - expect).abs().max())
+        out["grad_max"] = float(expect.abs().max())
+        out["shaded"] = int(model.last["ws"].counters2d[:, 0].sum())
+        del rgb      # with it goes the autograd graph of the default stream (see GraphedTrainStep's docstring)
+        print(f"[rank {rank}] eager exchange done", flush=True)
+        # 2. the split hipGraph step: same parameters on every rank after several steps, loss goes down
+        model.zero_grad(set_to_none=True)
+        opt = recon.FusedAdam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+        gs = recon.GraphedTrainStep(model, opt, ids.numel(), N, warmup=1)
+        out["split"] = gs.split
+        losses = []
+        for it in range(8):
+            losses.append(float(gs.step(rays, target, ids)))
+            print(f"[rank {rank}] graphed step {it} loss {losses[-1]:.5f}", flush=True)
+        torch.cuda.synchronize()
+        out["graphs"] = gs.graph is not None and gs.graph_opt is not None
+        out["losses"] = losses
+        digest = torch.stack([p.detach().double().sum() for p in model.parameters()])
+        both = [torch.empty_like(digest) for _ in range(world)]
+        dist.all_gather(both, digest)
+        out["same_params"] = bool(torch.equal(both[0], both[1]))
+        out["finite"] = all(bool(torch.isfinite(p).all()) for p in model.parameters())
+    except Exception as e:      # report instead of hanging the peer
+        import traceback
+        out["error"] = traceback.format_exc()
+    q.put(out)
+    dist.destroy_process_group()
+
+
+def test_two_rank_train_step_on_one_gpu():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=200) for _ in range(world)]
+    except Exception:
+        for p in procs:
+            p.join(timeout=5)
+        raise AssertionError(f"no result from the ranks; exit codes {[p.exitcode for p in procs]}")
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert "error" not in r, r["error"]
+        assert r["cells"] is not None and r["cells"] < 0.6 and r["shaded"] > 2000 and r["grad_max"] > 0, r
+        assert r["exchange_err"] <= 1e-6 * r["grad_max"], r
+        assert r["split"] and r["graphs"] and r["same_params"] and r["finite"], r
+        assert min(r["losses"][3:]) < r["losses"][0], r["losses"]
+    print("cells exchanged: %.1f %% of the gradient buffer" % (100 * res[0]["cells"]))

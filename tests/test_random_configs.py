@@ -23,6 +23,8 @@ def _draw(seed):
     comps = lambda choices: [int(g.choice(choices))] * (1 if cp else 1) if cp else [int(g.choice(choices)) for _ in range(3)]
     den = comps([4, 6, 8, 16, 20]) if not cp else [int(g.choice([8, 12, 30]))]
     app = comps([8, 12, 18, 24, 48]) if not cp else [int(g.choice([24, 40, 52]))]
+    if seed >= 100:     # wide appearance bases: the shading backward's gather-V-twice LDS layout (shade_bwd.hip bwd_lds)
+        app = [int(g.choice([64, 72, 96, 128])) for _ in range(3)] if not cp else [int(g.choice([192, 288, 384]))]
     args = dict(step_ratio=float(g.choice([0.5, 0.8])), fea2denseAct=str(g.choice(["softplus", "relu"])),
                 density_n_comp=den, app_n_comp=app, app_dim=int(g.choice([12, 16, 27])), density_shift=-10.0,
                 distance_scale=25.0, alphaMask_thres=0.001, shadingMode=head, pos_pe=int(g.integers(0, 4)),
@@ -62,7 +64,7 @@ def _build(recon, seed):
     return model, rays, ndc, args, mask
 
 
-@pytest.mark.parametrize("seed", list(range(40)))
+@pytest.mark.parametrize("seed", list(range(40)) + list(range(100, 108)))
 def test_random_configuration(recon, seed):
     model, rays, ndc, args, mask = _build(recon, seed)
     N = min(int(model.nSamples), 400)
