@@ -124,6 +124,8 @@ _SIGS = {
     "tf_pack_matrix": [_fp, C.c_int, C.c_int, _fp, C.c_int, _fp],
     "tf_pack_matrix_t": [_fp, C.c_int, C.c_int, _fp, C.c_int, _fp],
     "tf_pack_matrices": [C.POINTER(TfPackJob), _fp],
+    "tf_gather_rows": [_fp, _fp, C.c_int, C.c_int, _fp, _fp],
+    "tf_scatter_rows": [_fp, _fp, C.c_int, C.c_int, _fp, _fp],
     "tf_mse_grad": [_fp, _fp, C.c_int, C.c_float, _fp, _fp, _fp],
     "tf_generate_rays": [C.POINTER(TfCamera), _fp, C.c_longlong, C.c_int, _fp, _fp],
     "tf_march_forward": [C.POINTER(TfField), C.POINTER(TfMarchIO), _fp],

@@ -220,6 +220,19 @@ __global__ __launch_bounds__(64) void march_backward_kernel(const TfField F, con
     if (have) pair_commit(cur);
 }
 
+// One float4 per thread: element t of the packed side is quarter (t % q) of row idx[t / q] of the table.
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void move_rows_kernel(float* __restrict__ table, const int* __restrict__ idx,
+                                                        long long n4, int q, float* __restrict__ packed) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n4) return;
+    const long long row = idx[t / q];
+    float4* tp = reinterpret_cast<float4*>(table) + row * q + (t % q);
+    float4* pp = reinterpret_cast<float4*>(packed) + t;
+    if (SCATTER) *tp = *pp;
+    else *pp = *tp;
+}
+
 __global__ __launch_bounds__(256) void reduce_replicas_kernel(const float* __restrict__ rep, int n_rep, int stride,
                                                               int numel, float* __restrict__ dst) {
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < numel; j += gridDim.x * blockDim.x) {
@@ -232,6 +245,24 @@ __global__ __launch_bounds__(256) void reduce_replicas_kernel(const float* __res
 }  // namespace
 
 extern "C" {
+
+int tf_gather_rows(const float* table, const int* idx, int n_rows, int w, float* packed, tf_stream_t stream) {
+    if (n_rows <= 0) return 0;
+    if (w <= 0 || (w & 3)) return (int)hipErrorInvalidValue;
+    const long long n4 = (long long)n_rows * (w / 4);
+    hipLaunchKernelGGL((move_rows_kernel<false>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       const_cast<float*>(table), idx, n4, w / 4, packed);
+    return TF_CHECK_LAUNCH();
+}
+
+int tf_scatter_rows(float* table, const int* idx, int n_rows, int w, const float* packed, tf_stream_t stream) {
+    if (n_rows <= 0) return 0;
+    if (w <= 0 || (w & 3)) return (int)hipErrorInvalidValue;
+    const long long n4 = (long long)n_rows * (w / 4);
+    hipLaunchKernelGGL((move_rows_kernel<true>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       table, idx, n4, w / 4, const_cast<float*>(packed));
+    return TF_CHECK_LAUNCH();
+}
 
 int tf_reduce_replicas(const float* rep, int n_rep, int stride, int numel, float* dst, tf_stream_t stream) {
     if (numel <= 0) return 0;

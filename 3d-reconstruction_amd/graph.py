@@ -31,8 +31,8 @@ class GraphedTrainStep:
     def __init__(self, model, optimizer, batch, n_samples, mask=None, ndc_ray=False, warmup=3, split=None):
         self.model, self.opt = model, optimizer
         # split: capture backward and optimizer separately with the gradient all-reduce in between
-        self.split = (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) if split is None \
-            else bool(split)
+        self.split = (dist.is_available() and dist.is_initialized() and
+                      (dist.get_world_size() > 1 or parallel.FORCE_EXCHANGE)) if split is None else bool(split)
         self.graph_opt = None
         # data parallel: d loss / d rgb is pre-divided by the world size and the ranks' gradients are summed, which
         # equals averaging them without a second pass over the gradient buffer (1 / 2^k scales exactly)

@@ -7,9 +7,15 @@ already writes every gradient of a step into ONE contiguous fp32 buffer (`model.
 fully connected 8-GPU xGMI mesh one large all-reduce lets RCCL use all 7 links of every GPU at once.
 The reference has no multi-GPU code; nothing here mirrors a reference call pattern."""
 import math
+import os
 
 import torch
 import torch.distributed as dist
+
+
+# TF_DP_FORCE_EXCHANGE=1: run the gradient exchange (and the split-graph step built around it) even in a one-rank
+# group — a rehearsal of the N > 1 code path, RCCL included, on a single GPU
+FORCE_EXCHANGE = bool(int(os.environ.get("TF_DP_FORCE_EXCHANGE", "0")))
 
 
 def shard_ids(ids: torch.Tensor, rank: int, world: int) -> torch.Tensor:
@@ -155,7 +161,7 @@ def gradient_support_rows(model):
         idx = torch.sort(torch.cat(pieces))[0]
         if idx.numel() * w < 0.9 * grad_len:
             result = (w, idx)
-    model._rows_cache = (result, mask, offs, geom)
+    model._rows_cache = (result, mask, offs, geom, None if result is None else result[1].to(torch.int32))
     return result
 
 
@@ -168,7 +174,7 @@ def allreduce_gradients(model, group=None, average=True, use_support=True):
     if not dist.is_available() or not dist.is_initialized():
         return
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not FORCE_EXCHANGE:
         return
     flat = getattr(model, "grad_flat", None)
     params = [p for p in model.parameters() if p.grad is not None]
@@ -179,11 +185,23 @@ def allreduce_gradients(model, group=None, average=True, use_support=True):
         if rows is not None:
             w, idx = rows
             table = flat.view(-1, w)
-            buf = table.index_select(0, idx)                             # one gather launch
+            if flat.is_cuda:                                             # tf_gather_rows / tf_scatter_rows: float4 moves
+                from . import _hip as H
+                from .field import _stream
+                idx32 = model._rows_cache[4]
+                buf = torch.empty(idx.numel(), w, dtype=torch.float32, device=flat.device)
+                H.check(H.lib().tf_gather_rows(flat.data_ptr(), idx32.data_ptr(), idx.numel(), w, buf.data_ptr(),
+                                               _stream()), "tf_gather_rows")
+            else:
+                buf = table.index_select(0, idx)
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
             if average:
                 buf.mul_(1.0 / world)
-            table.index_copy_(0, idx, buf)
+            if flat.is_cuda:
+                H.check(H.lib().tf_scatter_rows(flat.data_ptr(), idx32.data_ptr(), idx.numel(), w, buf.data_ptr(),
+                                                _stream()), "tf_scatter_rows")
+            else:
+                table.index_copy_(0, idx, buf)
             return
         segs = gradient_support(model) if use_support else None
         if segs is None:

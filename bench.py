@@ -166,8 +166,11 @@ def main():
     # the driver's runs use the default, "nccl" (= RCCL), one rank per GPU
     backend = os.environ.get("TF_DIST_BACKEND", "nccl")
     local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
-    if world > 1:
+    if world > 1 or int(os.environ.get("TF_DP_FORCE_EXCHANGE", "0")):     # the latter: 1-rank rehearsal of the N > 1 path
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         if backend == "nccl":
@@ -253,7 +256,7 @@ def main():
         step(i)
     model.kernel_events = {}
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -265,11 +268,11 @@ def main():
             ctr_sum += model.last["ws"].counters2d[:, :3].sum(0)
     host_issue = time.perf_counter() - t0        # host time to enqueue the timed steps (diagnostic: host- vs GPU-bound)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
@@ -357,7 +360,7 @@ def main():
                                                      f"restatement run eagerly on this GPU (PyTorch-ROCm path)",
                                            "speedup": value / v2}
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -295,6 +295,12 @@ int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream);
 /* dst[j] = sum_r rep[r*stride + j], j < numel: folds the line-gradient replicas. */
 int tf_reduce_replicas(const float* rep, int n_rep, int stride, int numel, float* dst, tf_stream_t stream);
 
+/* Row gather / write-back of the data-parallel gradient exchange (parallel.py): `table` is the step's gradient buffer
+ * viewed as rows of `w` floats (w % 4 == 0, 16-byte aligned), `idx` the n_rows row numbers that can be non-zero.
+ * tf_gather_rows: packed[j] = table[idx[j]];  tf_scatter_rows: table[idx[j]] = packed[j] (idx holds no duplicates). */
+int tf_gather_rows(const float* table, const int* idx, int n_rows, int w, float* packed, tf_stream_t stream);
+int tf_scatter_rows(float* table, const int* idx, int n_rows, int w, const float* packed, tf_stream_t stream);
+
 /* ---- regularisers of the training loop, TensorVMSplit ---------------------------------
  * loss[0] += w_ortho * vector_comp_diffs() + w_l1 * density_L1() + w_tv_density * TV_loss_density(TVLoss())
  *            + w_tv_app * TV_loss_app(TVLoss())            (train.py:340-371, tensoRF.py:175-205, loss.py:120-141)

@@ -26,6 +26,14 @@ for name in sys.argv[1:] or ["C2_vm300"]:
     cat = torch.cat(pieces)
     sizes = [p.numel() for p in pieces]
     print(f"{name}: buffer {flat.numel()*4/1e6:.1f} MB; row blocks {cat.numel()*4/1e6:.1f} MB; cells {buf.numel()*4/1e6:.1f} MB (rows of {w} floats)")
-    print(f"  cells : gather {t(lambda: table.index_select(0, idx)):.1f} us, write-back {t(lambda: table.index_copy_(0, idx, buf)):.1f} us")
+    from recon_amd import _hip as H
+    from recon_amd.field import _stream
+    idx32 = idx.to(torch.int32)
+    g = lambda: H.lib().tf_gather_rows(flat.data_ptr(), idx32.data_ptr(), idx.numel(), w, buf.data_ptr(), _stream())
+    sc = lambda: H.lib().tf_scatter_rows(flat.data_ptr(), idx32.data_ptr(), idx.numel(), w, buf.data_ptr(), _stream())
+    ref = table.index_select(0, idx); g(); torch.cuda.synchronize()
+    assert torch.equal(ref, buf)
+    print(f"  cells (tf_gather_rows / tf_scatter_rows): gather {t(g):.1f} us, write-back {t(sc):.1f} us")
+    print(f"  cells (torch index_select / index_copy_): gather {t(lambda: table.index_select(0, idx)):.1f} us, write-back {t(lambda: table.index_copy_(0, idx, buf)):.1f} us")
     print(f"  blocks: cat {t(lambda: torch.cat(pieces)):.1f} us, write-back {t(lambda: torch._foreach_copy_(pieces, list(cat.split(sizes)))):.1f} us, "
           f"scale pass {t(lambda: cat.mul_(0.5)):.1f} us")
