@@ -89,6 +89,9 @@ __device__ __forceinline__ void sample_keys(const KeyMap& K, const int grid[3], 
             { const int key = (keys)[3 + _i] + _g * (K).lbuckets[_i]; BODY; } \
         }
 
+// threads per workgroup and workgroups per entry shard of the count / fill passes (measured at config 2:
+// 1 / 2 / 4 / 8 / 16 slices -> count 23 / 15 / 12.5 / 15 / 22 us, fill 50 / 32 / 24 / 31 / 50 us; 1024 threads: no change)
+constexpr int kSortThreads = 256;
 constexpr int kSlices = 4;   // workgroups per entry shard in the count / fill passes
 
 // (a kernel rather than hipMemsetAsync: the memset issued from this library was not replayed by a captured
@@ -102,15 +105,15 @@ constexpr int kKeyRange = 16384;   // keys per LDS pass of the count / scan / fi
 // entries of shard g handled by slice k: local = k*256 + tid, += kSlices*256.  Jobs with more than kKeyRange keys
 // (grids beyond ~400^3 at 48 components) are counted in passes over key ranges; the entries of a workgroup are
 // few (cnt / kSlices), so re-deriving their keys per pass is cheap next to the LDS table work.
-__global__ __launch_bounds__(256) void bin_count_kernel(const TfBinJob J, const KeyMap K) {
+__global__ __launch_bounds__(kSortThreads) void bin_count_kernel(const TfBinJob J, const KeyMap K) {
     extern __shared__ int lh[];
     const int g = blockIdx.x / kSlices, k = blockIdx.x % kSlices;
     const int cnt = J.counters[g * TF_SHARD_STRIDE + J.slot];
     for (int k0 = 0; k0 < K.nkeys; k0 += kKeyRange) {
         const int kn = min(kKeyRange, K.nkeys - k0);
-        for (int i = threadIdx.x; i < kn; i += 256) lh[i] = 0;
+        for (int i = threadIdx.x; i < kn; i += kSortThreads) lh[i] = 0;
         __syncthreads();
-        for (int local = k * 256 + threadIdx.x; local < cnt; local += kSlices * 256) {
+        for (int local = k * kSortThreads + threadIdx.x; local < cnt; local += kSlices * kSortThreads) {
             const size_t e = (size_t)g * J.seg_cap + local;
             const float u[3] = {J.xyz[e * 3], J.xyz[e * 3 + 1], J.xyz[e * 3 + 2]};
             SampleGeom sg;
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(const TfBinJob J, const 
             TF_FOR_EACH_KEY(K, keys, key, if ((unsigned)(key - k0) < (unsigned)kn) atomicAdd(&lh[key - k0], 1));
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < kn; i += 256)
+        for (int i = threadIdx.x; i < kn; i += kSortThreads)
             if (lh[i]) atomicAdd(&J.hist[k0 + i], lh[i]);
         __syncthreads();
     }
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(const TfBinJob J, int nk
     }
 }
 
-__global__ __launch_bounds__(256) void bin_fill_kernel(const TfBinJob J, const KeyMap K) {
+__global__ __launch_bounds__(kSortThreads) void bin_fill_kernel(const TfBinJob J, const KeyMap K) {
     extern __shared__ int lds[];
     int* lh = lds;               // counts, then running ranks
     int* lb = lds + min(K.nkeys, kKeyRange);   // reserved base per key
@@ -224,9 +227,9 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(const TfBinJob J, const K
     const int cnt = J.counters[g * TF_SHARD_STRIDE + J.slot];
     for (int k0 = 0; k0 < K.nkeys; k0 += kKeyRange) {     // key ranges, as in bin_count_kernel
         const int kn = min(kKeyRange, K.nkeys - k0);
-        for (int i = threadIdx.x; i < kn; i += 256) lh[i] = 0;
+        for (int i = threadIdx.x; i < kn; i += kSortThreads) lh[i] = 0;
         __syncthreads();
-        for (int local = k * 256 + threadIdx.x; local < cnt; local += kSlices * 256) {
+        for (int local = k * kSortThreads + threadIdx.x; local < cnt; local += kSlices * kSortThreads) {
             const size_t e = (size_t)g * J.seg_cap + local;
             const float u[3] = {J.xyz[e * 3], J.xyz[e * 3 + 1], J.xyz[e * 3 + 2]};
             SampleGeom sg;
@@ -236,12 +239,12 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(const TfBinJob J, const K
             TF_FOR_EACH_KEY(K, keys, key, if ((unsigned)(key - k0) < (unsigned)kn) atomicAdd(&lh[key - k0], 1));
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < kn; i += 256) {
+        for (int i = threadIdx.x; i < kn; i += kSortThreads) {
             lb[i] = lh[i] ? atomicAdd(&J.cursor[k0 + i], lh[i]) : 0;
             lh[i] = 0;
         }
         __syncthreads();
-        for (int local = k * 256 + threadIdx.x; local < cnt; local += kSlices * 256) {
+        for (int local = k * kSortThreads + threadIdx.x; local < cnt; local += kSlices * kSortThreads) {
             const size_t e = (size_t)g * J.seg_cap + local;
             const float u[3] = {J.xyz[e * 3], J.xyz[e * 3 + 1], J.xyz[e * 3 + 2]};
             SampleGeom sg;
@@ -504,7 +507,7 @@ int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(sizeof(int) * kr));
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(bin_count_kernel, dim3(TF_N_SHARDS * kSlices), dim3(256), sizeof(int) * kr, st, *job, K);
+    hipLaunchKernelGGL(bin_count_kernel, dim3(TF_N_SHARDS * kSlices), dim3(kSortThreads), sizeof(int) * kr, st, *job, K);
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(sizeof(int) * kr));
     if (e != hipSuccess) return (int)e;
@@ -512,7 +515,7 @@ int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(sizeof(int) * 2 * kr));
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(bin_fill_kernel, dim3(TF_N_SHARDS * kSlices), dim3(256), sizeof(int) * 2 * kr, st, *job, K);
+    hipLaunchKernelGGL(bin_fill_kernel, dim3(TF_N_SHARDS * kSlices), dim3(kSortThreads), sizeof(int) * 2 * kr, st, *job, K);
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)sc_bytes);
     if (e != hipSuccess) return (int)e;
