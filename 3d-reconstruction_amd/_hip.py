@@ -47,7 +47,7 @@ class TfMarchIO(C.Structure):
                 ("acc", _fp), ("depth", _fp), ("app_offset", _fp), ("app_count", _fp), ("val_count", _fp),
                 ("counters", _fp), ("app_ray", _fp), ("app_xyz", _fp), ("app_w", _fp),
                 ("val_idx", _fp), ("val_feat", _fp), ("dbg_bbox_bits", _fp), ("dbg_valid_bits", _fp),
-                ("dbg_app_bits", _fp)]
+                ("dbg_app_bits", _fp), ("ent_xyz", _fp), ("ent_offset", _fp)]
 
 
 class TfPeBlock(C.Structure):
@@ -72,7 +72,7 @@ class TfBinJob(C.Structure):
                 ("slot", C.c_int), ("seg_cap", C.c_int), ("xyz", _fp), ("grad", _fp), ("grad_ld", C.c_int),
                 ("tile", C.c_int), ("bucket", C.c_int), ("chunk", C.c_int),
                 ("hist", _fp), ("offsets", _fp), ("cursor", _fp), ("chunk_off", _fp), ("binned", _fp),
-                ("nkeys", C.c_int), ("hist_zeroed", C.c_int)]
+                ("nkeys", C.c_int), ("hist_zeroed", C.c_int), ("stage", C.c_int)]
 
 
 class TfCamera(C.Structure):
@@ -129,7 +129,7 @@ _SIGS = {
     "tf_mse_grad": [_fp, _fp, C.c_int, C.c_float, _fp, _fp, _fp],
     "tf_generate_rays": [C.POINTER(TfCamera), _fp, C.c_longlong, C.c_int, _fp, _fp],
     "tf_march_forward": [C.POINTER(TfField), C.POINTER(TfMarchIO), _fp],
-    "tf_shade_forward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp],
+    "tf_shade_forward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, C.c_int, _fp],
     "tf_composite_forward": [C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp],
     "tf_density_points": [C.POINTER(TfField), _fp, C.c_int, _fp, _fp],
     "tf_appfeature_points": [C.POINTER(TfShade), _fp, C.c_int, _fp, _fp],

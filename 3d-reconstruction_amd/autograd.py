@@ -41,11 +41,57 @@ def _grad_buffers(named, n_rep=N_REP):
     return views, flat, offs, total, line_len
 
 
+def _bin_job(model, ws, part, factors, grid, stage, fgrads=None, grad=None, grad_ld=0):
+    """TfBinJob of the density / appearance gradient scatter; every job owns its sort workspace."""
+    app = part == "app"
+    nkeys = ws.binned_cfg[1 if app else 0]
+    nmax = max(ws.binned_cfg[0], ws.binned_cfg[1])
+    j = H.TfBinJob()
+    j.model = H.MODEL_CP if model._is_cp() else H.MODEL_VM
+    j.factors = factors
+    if fgrads is not None:
+        j.grads = fgrads
+    j.grid = grid
+    j.counters, j.slot, j.seg_cap = ws.counters.data_ptr(), (0 if app else 3), ws.seg_cap
+    j.xyz = (ws.app_xyz if app else ws.ent_xyz).data_ptr()
+    j.grad, j.grad_ld = (grad.data_ptr() if grad is not None else None), grad_ld
+    j.tile, j.bucket, j.chunk = ws.binned_cfg[3], model.bin_bucket, model.bin_chunk
+    ints = (ws.bin_ints_app if app else ws.bin_ints).data_ptr()
+    j.hist = (ws.hist_app if app else ws.hist_density).data_ptr()
+    j.hist_zeroed = 1                     # zeroed with the shard counters at the start of the forward
+    j.offsets = ints
+    j.cursor, j.chunk_off = ints + 4 * (nmax + 8), ints + 8 * (nmax + 8)
+    j.binned, j.nkeys = (ws.binned_app if app else ws.binned).data_ptr(), nkeys
+    j.stage = stage
+    return j
+
+
+def _early_sort(model, ws, field, shade):
+    """Fork: both entry lists of the backward's binned scatter are complete once tf_march_forward has run (the
+    appearance samples' coordinates, and — TfMarchIO.ent_xyz — the density samples'), so their counting sorts
+    (three small, latency-bound kernels each) are issued on a second stream here and run next to the shading
+    kernels.  The backward joins before its first scatter.  Works the same inside a hipGraph capture."""
+    main = torch.cuda.current_stream()
+    if model._sort_stream is None:
+        model._sort_stream = torch.cuda.Stream(device=main.device, priority=-1)   # its few workgroups go first
+    side = model._sort_stream
+    side.wait_stream(main)
+    lib = H.lib()
+    with torch.cuda.stream(side):
+        st = _stream()
+        model._timed("tf_bin_sort_density", lib.tf_binned_scatter,
+                     C.byref(_bin_job(model, ws, "density", field.density, field.grid, 1)), st)
+        model._timed("tf_bin_sort_app", lib.tf_binned_scatter,
+                     C.byref(_bin_job(model, ws, "app", shade.app, field.grid, 1)), st)
+    return side
+
+
 class _RenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, rays, mask, white_bg, is_train, ndc_ray, N_samples, names, *params):
         ctx.set_materialize_grads(False)     # no zero-filled gradients for the two non-differentiable results
-        c = model._run_forward(rays, mask, white_bg, is_train, ndc_ray, N_samples, save_valid=True)
+        c = model._run_forward(rays, mask, white_bg, is_train, ndc_ray, N_samples, save_valid=True,
+                               after_march=lambda ws, field, shade: _early_sort(model, ws, field, shade))
         ws = c['ws']
         ctx.model, ctx.c, ctx.names = model, c, names
         ctx.versions = [p._version for p in params]
@@ -87,29 +133,19 @@ class _RenderFn(torch.autograd.Function):
                 if not cp:
                     fg.plane[i] = grads[f'{kind}_plane.{i}'].data_ptr()
                 fg.line[i] = rep0 + 4 * offs[f'{kind}_line.{i}']
-        def bin_job(factors, fgrads, slot, xyz, grad, grad_ld, part):
-            nkeys = ws.binned_cfg[0 if part == "density" else 1]
-            nmax = max(ws.binned_cfg[0], ws.binned_cfg[1])
-            j = H.TfBinJob()
-            j.model = H.MODEL_CP if cp else H.MODEL_VM
-            j.factors, j.grads = factors, fgrads
-            j.grid = c['field'].grid
-            j.counters, j.slot, j.seg_cap = ws.counters.data_ptr(), slot, ws.seg_cap
-            j.xyz, j.grad, j.grad_ld = xyz.data_ptr(), grad.data_ptr(), grad_ld
-            j.tile, j.bucket, j.chunk = ws.binned_cfg[3], model.bin_bucket, model.bin_chunk
-            ints = ws.bin_ints.data_ptr()
-            j.hist = (ws.hist_density if part == "density" else ws.hist_app).data_ptr()
-            j.hist_zeroed = 1                     # zeroed with the shard counters at the start of the forward
-            j.offsets = ints
-            j.cursor, j.chunk_off = ints + 4 * (nmax + 8), ints + 8 * (nmax + 8)
-            j.binned, j.nkeys = ws.binned.data_ptr(), nkeys
+        presorted = c.get('sorted_on') is not None
+        def bin_job(factors, fgrads, grad, grad_ld, part):
+            j = _bin_job(model, ws, part, factors, c['field'].grid, 2 if presorted else 0, fgrads, grad, grad_ld)
             model._timed("tf_binned_scatter_" + part, lib.tf_binned_scatter, C.byref(j), st)
 
         model._timed("tf_march_backward", lib.tf_march_backward, C.byref(c['field']), C.byref(c['io']), g.data_ptr(),
                      ws.rgb_pre.data_ptr(), int(c['use_bg']), ws.rgb.data_ptr(), ws.grad_rgb.data_ptr(), C.byref(dg),
                      ws.ent_xyz.data_ptr() if binned else None, ws.ent_df.data_ptr() if binned else None, st)
         if binned:
-            bin_job(c['field'].density, dg, 3, ws.ent_xyz, ws.ent_df, 0, "density")
+            if presorted:       # join the second stream (one cross-stream wait costs ~8 us of launch latency, so
+                # there is only this one: both sorts have long finished when march_backward ends)
+                torch.cuda.current_stream().wait_stream(c['sorted_on'])
+            bin_job(c['field'].density, dg, ws.ent_df, 0, "density")
         sg = H.TfShadeGrads()
         sg.w1, sg.b1 = grads['renderModule.mlp.0.weight'].data_ptr(), grads['renderModule.mlp.0.bias'].data_ptr()
         sg.w2, sg.b2 = grads['renderModule.mlp.2.weight'].data_ptr(), grads['renderModule.mlp.2.bias'].data_ptr()
@@ -122,7 +158,7 @@ class _RenderFn(torch.autograd.Function):
                      int(c['ndc']), ws.counters.data_ptr(), ws.seg_cap, ws.app_ray.data_ptr(), ws.app_xyz.data_ptr(),
                      ws.grad_rgb.data_ptr(), C.byref(sg), st)
         if binned:
-            bin_job(c['shade'].app, ag, 0, ws.app_xyz, ws.dv, model._n_app_total(), "app")
+            bin_job(c['shade'].app, ag, ws.dv, model._n_app_total(), "app")
         if n_rep:
             model._timed("tf_reduce_replicas", lib.tf_reduce_replicas, rep0, n_rep, line_len, line_len, flat.data_ptr(), st)
         out = tuple(grads[n] if p.requires_grad else None for n, p in named)

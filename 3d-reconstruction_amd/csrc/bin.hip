@@ -132,27 +132,30 @@ __global__ __launch_bounds__(kSortThreads) void bin_count_kernel(const TfBinJob 
 // offsets[] = exclusive prefix of hist[], chunk_off[] = exclusive prefix of ceil(hist/chunk); cursor = offsets.
 // One workgroup walks the keys in ranges of kKeyRange with a running carry: the range's histogram is pulled into
 // LDS with coalesced loads first — every later pass touches LDS only (per-thread strided global reads made this
-// kernel a chain of memory latencies).
-__global__ __launch_bounds__(1024) void bin_scan_kernel(const TfBinJob J, int nkeys, int csh /* log2(J.chunk) */) {
-    extern __shared__ int sh[];                 // hist copy of the current key range
-    __shared__ int part[16], part2[16];
+// kernel a chain of memory latencies).  The kernel is kept SMALL on purpose (no per-thread register copy of the
+// histogram slice: 1024 threads at 128 VGPRs need a whole empty CU, and the training step runs this kernel next to
+// tf_shade_forward on a second stream).
+__global__ __launch_bounds__(1024, 8) void bin_scan_kernel(const TfBinJob J, int nkeys, int csh /* log2(J.chunk) */) {
+    extern __shared__ int sh[];                 // hist copy of the current key range, then its prefixes
+    __shared__ int part[17], part2[17];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // item table: work item -> key (chunk index = item - chunk_off[key]); lives behind chunk_off[]
     int* items = J.chunk_off + nkeys + 1;
+    const int cm1 = J.chunk - 1;
     int carry = 0, carry2 = 0;
     for (int k0 = 0; k0 < nkeys; k0 += kKeyRange) {
         const int kn = min(kKeyRange, nkeys - k0);
         __syncthreads();                        // the previous range's copy-out has finished reading sh / part
         for (int i = tid; i < kn; i += 1024) sh[i] = J.hist[k0 + i];
         __syncthreads();
-        constexpr int kPer = kKeyRange / 1024;  // per-thread histogram slice, kept in registers
+        constexpr int kPer = kKeyRange / 1024;  // keys per thread (contiguous)
         const int lo = tid * kPer, hi = min(kn, (tid + 1) * kPer);
-        int h[kPer], s = 0, s2 = 0;
-#pragma unroll
-        for (int q = 0; q < kPer; ++q) {
-            h[q] = lo + q < hi ? sh[lo + q] : 0;
-            s += h[q];
-            s2 += (h[q] + J.chunk - 1) >> csh;
+        int s = 0, s2 = 0;
+#pragma unroll 1
+        for (int i = lo; i < hi; ++i) {
+            const int h = sh[i];
+            s += h;
+            s2 += (h + cm1) >> csh;
         }
         // inclusive scan over the 1024 threads: shuffles inside each wave, then the 16 wave totals
         int v = s, v2 = s2;
@@ -169,29 +172,39 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(const TfBinJob J, int nk
             part2[wv] = v2;
         }
         __syncthreads();
-        int wbase = 0, wbase2 = 0, tot = 0, tot2 = 0;
+        if (wv == 0) {      // exclusive scan of the 16 wave totals; slot 16 = grand total
+            int a = lane < 16 ? part[lane] : 0, b = lane < 16 ? part2[lane] : 0;
+            const int a0 = a, b0 = b;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const int a = part[w], b = part2[w];
-            if (w < wv) {
-                wbase += a;
-                wbase2 += b;
+            for (int o = 1; o < 16; o <<= 1) {
+                const int x = __shfl_up(a, o, 64), y = __shfl_up(b, o, 64);
+                if (lane >= o) {
+                    a += x;
+                    b += y;
+                }
             }
-            tot += a;
-            tot2 += b;
+            if (lane < 16) {
+                part[lane] = a - a0;
+                part2[lane] = b - b0;
+            }
+            if (lane == 15) {
+                part[16] = a;
+                part2[16] = b;
+            }
         }
+        __syncthreads();
+        const int wbase = part[wv], wbase2 = part2[wv], tot = part[16], tot2 = part2[16];
         // The per-thread key ranges are contiguous, so writing the prefixes straight to global memory would be one
         // cache line per lane and store; they go to LDS (in place of the histogram) and leave with coalesced stores.
         int run = carry + v + wbase - s, run2 = carry2 + v2 + wbase2 - s2;
-#pragma unroll
-        for (int q = 0; q < kPer; ++q) {
-            if (lo + q < hi) {
-                sh[lo + q] = run;
-                const int nc = (h[q] + J.chunk - 1) >> csh;
-                for (int c = 0; c < nc; ++c) items[run2 + c] = k0 + lo + q;
-                run += h[q];
-                run2 += nc;
-            }
+#pragma unroll 1
+        for (int i = lo; i < hi; ++i) {
+            const int h = sh[i];
+            sh[i] = run;
+            const int nc = (h + cm1) >> csh;
+            for (int c = 0; c < nc; ++c) items[run2 + c] = k0 + i;
+            run += h;
+            run2 += nc;
         }
         __syncthreads();
         for (int i = tid; i < kn; i += 1024) {
@@ -200,13 +213,16 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(const TfBinJob J, int nk
             J.cursor[k0 + i] = o;
         }
         __syncthreads();
+        // chunk prefixes: the counts are recovered from neighbouring offsets (sh holds them; the end of the thread's
+        // slice is `run`)
         run2 = carry2 + v2 + wbase2 - s2;
-#pragma unroll
-        for (int q = 0; q < kPer; ++q) {
-            if (lo + q < hi) {
-                sh[lo + q] = run2;
-                run2 += (h[q] + J.chunk - 1) >> csh;
-            }
+        int prev = lo < hi ? sh[lo] : 0;
+#pragma unroll 1
+        for (int i = lo; i < hi; ++i) {
+            const int next = i + 1 < hi ? sh[i + 1] : run;
+            sh[i] = run2;
+            run2 += (next - prev + cm1) >> csh;
+            prev = next;
         }
         __syncthreads();
         for (int i = tid; i < kn; i += 1024) J.chunk_off[k0 + i] = sh[i];
@@ -220,9 +236,7 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(const TfBinJob J, int nk
 }
 
 __global__ __launch_bounds__(kSortThreads) void bin_fill_kernel(const TfBinJob J, const KeyMap K) {
-    extern __shared__ int lds[];
-    int* lh = lds;               // counts, then running ranks
-    int* lb = lds + min(K.nkeys, kKeyRange);   // reserved base per key
+    extern __shared__ int lh[];  // per key: this workgroup's count, then its running write position in `binned`
     const int g = blockIdx.x / kSlices, k = blockIdx.x % kSlices;
     const int cnt = J.counters[g * TF_SHARD_STRIDE + J.slot];
     for (int k0 = 0; k0 < K.nkeys; k0 += kKeyRange) {     // key ranges, as in bin_count_kernel
@@ -239,9 +253,9 @@ __global__ __launch_bounds__(kSortThreads) void bin_fill_kernel(const TfBinJob J
             TF_FOR_EACH_KEY(K, keys, key, if ((unsigned)(key - k0) < (unsigned)kn) atomicAdd(&lh[key - k0], 1));
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < kn; i += kSortThreads) {
-            lb[i] = lh[i] ? atomicAdd(&J.cursor[k0 + i], lh[i]) : 0;
-            lh[i] = 0;
+        for (int i = threadIdx.x; i < kn; i += kSortThreads) {     // reserve this workgroup's range of every key it holds
+            const int c = lh[i];
+            if (c) lh[i] = atomicAdd(&J.cursor[k0 + i], c);
         }
         __syncthreads();
         for (int local = k * kSortThreads + threadIdx.x; local < cnt; local += kSlices * kSortThreads) {
@@ -252,7 +266,7 @@ __global__ __launch_bounds__(kSortThreads) void bin_fill_kernel(const TfBinJob J
             int keys[6];
             sample_keys(K, J.grid, sg, keys);
             TF_FOR_EACH_KEY(K, keys, key,
-                            if ((unsigned)(key - k0) < (unsigned)kn) J.binned[lb[key - k0] + atomicAdd(&lh[key - k0], 1)] = (int)e);
+                            if ((unsigned)(key - k0) < (unsigned)kn) J.binned[atomicAdd(&lh[key - k0], 1)] = (int)e);
         }
         __syncthreads();
     }
@@ -502,20 +516,25 @@ int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream) {
     int per_cu = (int)((160 * 1024) / (sc_bytes + 512));
     per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
     hipError_t e = hipSuccess;
-    if (!job->hist_zeroed)
-        hipLaunchKernelGGL(zero_ints_kernel, dim3((K.nkeys + 255) / 256), dim3(256), 0, st, job->hist, K.nkeys);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(sizeof(int) * kr));
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(bin_count_kernel, dim3(TF_N_SHARDS * kSlices), dim3(kSortThreads), sizeof(int) * kr, st, *job, K);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(sizeof(int) * kr));
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), sizeof(int) * kr, st, *job, K.nkeys, csh);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(sizeof(int) * 2 * kr));
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(bin_fill_kernel, dim3(TF_N_SHARDS * kSlices), dim3(kSortThreads), sizeof(int) * 2 * kr, st, *job, K);
+    if (job->stage < 0 || job->stage > 2) return (int)hipErrorInvalidValue;
+    if (job->stage != 2) {      // sort: count -> scan -> fill
+        if (!job->hist_zeroed)
+            hipLaunchKernelGGL(zero_ints_kernel, dim3((K.nkeys + 255) / 256), dim3(256), 0, st, job->hist, K.nkeys);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(int) * kr));
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(bin_count_kernel, dim3(TF_N_SHARDS * kSlices), dim3(kSortThreads), sizeof(int) * kr, st, *job, K);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(int) * kr));
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), sizeof(int) * kr, st, *job, K.nkeys, csh);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(int) * kr));
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(bin_fill_kernel, dim3(TF_N_SHARDS * kSlices), dim3(kSortThreads), sizeof(int) * kr, st, *job, K);
+        if (job->stage == 1) return TF_CHECK_LAUNCH();
+    }
+    if (!job->grad) return (int)hipErrorInvalidValue;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)sc_bytes);
     if (e != hipSuccess) return (int)e;

@@ -165,6 +165,25 @@ __global__ __launch_bounds__(64) void march_forward_kernel(const TfField F, cons
         io.app_count[r] = appcnt;
         io.val_count[r] = done;
     }
+    if (io.ent_xyz) {      // density entry list of the binned backward scatter: coordinates now, dL/df in the backward
+        __syncthreads();   // val_idx was written by other lanes of this wave
+        int eb = 0;
+        if (lane == 0) {
+            const int seg_cap = ((gridDim.x + kShards - 1) / kShards) * N;
+            eb = shard * seg_cap + (done ? atomicAdd(&io.counters[shard * kShardStride + 3], done) : 0);
+            io.ent_offset[r] = eb;
+        }
+        eb = __shfl(eb, 0, 64);
+        for (int k = lane; k < done; k += 64) {
+            float p[3], u[3];
+            sample_pos(ray, sample_z(F, ray, ztab, io.val_idx[vbase + k]), p);
+            normalize(F, p, u);
+            const size_t e = (size_t)eb + k;
+            io.ent_xyz[e * 3] = u[0];
+            io.ent_xyz[e * 3 + 1] = u[1];
+            io.ent_xyz[e * 3 + 2] = u[2];
+        }
+    }
     base = __shfl(base, 0, 64);
     for (int j = lane; j < appcnt; j += 64) {
         const int idx = q[j];

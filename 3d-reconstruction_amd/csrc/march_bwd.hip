@@ -158,6 +158,11 @@ __global__ __launch_bounds__(64) void march_backward_kernel(const TfField F, con
     // ---------------- pass 3: scatter
     if (B.ent_xyz) {
         // binned mode: hand every valid sample (xyz, dL/df) to tf_binned_scatter through the sharded entry list
+        if (io.ent_offset) {      // the forward placed the entries (and wrote their coordinates) already
+            const size_t base = (size_t)io.ent_offset[r];
+            for (int k = lane; k < cnt; k += 64) B.ent_df[base + k] = sd[k];
+            return;
+        }
         const int shard = blockIdx.x & (TF_N_SHARDS - 1);
         int base = 0;
         if (lane == 0) {

@@ -306,9 +306,10 @@ int launch_shade(const TfShade* S, const TileSrc& src, float* rgb_out, float* fe
 extern "C" {
 
 int tf_shade_forward(const TfShade* shade, const float* rays, int ndc, const int* counters, int seg_cap,
-                     const int* app_ray, const float* app_xyz, float* rgb_out, tf_stream_t stream) {
+                     const int* app_ray, const float* app_xyz, float* rgb_out, int max_workgroups, tf_stream_t stream) {
     TileSrc src{counters, seg_cap, 0, app_ray, app_xyz, rays, ndc};
-    return launch_shade(shade, src, rgb_out, nullptr, 512, (hipStream_t)stream);
+    const int wgs = max_workgroups > 0 && max_workgroups < 512 ? max_workgroups : 512;
+    return launch_shade(shade, src, rgb_out, nullptr, wgs, (hipStream_t)stream);
 }
 
 int tf_appfeature_points(const TfShade* shade, const float* xyz_n, int n, float* out_feat, tf_stream_t stream) {

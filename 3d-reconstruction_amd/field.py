@@ -175,9 +175,11 @@ class _Workspace:
             spec += [("dv", cap * n_app, torch.float32), ("wslab", wslab, torch.float32)]
             if binned is not None:   # binned gradient scatter (csrc/bin.hip): entry lists + sort workspace
                 nkeys, kpe = max(binned[0], binned[1]), binned[2]
-                spec += [("ent_xyz", cap * 3, torch.float32), ("ent_df", cap, torch.float32),
-                         ("binned", kpe * cap, torch.int32),
-                         ("bin_ints", 4 * (nkeys + 8) + kpe * cap // 256 + 64, torch.int32)]
+                n_ints = 4 * (nkeys + 8) + kpe * cap // 256 + 64
+                # one sort workspace per job (density, appearance): both sorts run early, next to the shading kernels
+                spec += [("ent_xyz", cap * 3, torch.float32), ("ent_df", cap, torch.float32), ("ent_offset", R, torch.int32),
+                         ("binned", kpe * cap, torch.int32), ("bin_ints", n_ints, torch.int32),
+                         ("binned_app", kpe * cap, torch.int32), ("bin_ints_app", n_ints, torch.int32)]
         if debug:
             spec += [("dbg_bbox", R * words * 2, torch.int32), ("dbg_valid", R * words * 2, torch.int32),
                      ("dbg_app", R * words * 2, torch.int32)]
@@ -233,6 +235,11 @@ class TensorBase(nn.Module):
         self.t_stop = 0.0              # early ray termination threshold on transmittance (0 = off)
         self.count_samples = True      # False: forward() skips the num_valid_samples reduction (its 3rd result is then undefined)
         self.binned_scatter = True     # backward: counting-sorted LDS scatter (csrc/bin.hip) instead of per-tap atomics
+        self.early_sort = True         # sort the scatter's entries on a second stream right after the march kernel
+        self._sort_stream = None
+        # tf_shade_forward workgroups (of 512 CU slots) while the early sorts run next to it; the sort kernels need a CU
+        # slot's LDS and registers (measured at config 2: 512 / 480 / 448 / 416 / 384 -> 0.939 / 0.936 / 0.930 / 0.928 / 0.929 ms per step)
+        self.shade_wgs_beside_sort = 448
         self.bin_tile, self.bin_bucket, self.bin_chunk = 8, 8, 512
         self._jitter_override = None   # tests: inject the stratified jitter instead of drawing it
         self.static_jitter = None      # graph capture: device tensor (R,) the harness refills before every replay
@@ -587,7 +594,7 @@ class TensorBase(nn.Module):
         ev.setdefault(name, []).append((a, b))
 
     # ---- forward -------------------------------------------------------------------------------
-    def _run_forward(self, rays, mask, white_bg, is_train, ndc_ray, N_samples, save_valid):
+    def _run_forward(self, rays, mask, white_bg, is_train, ndc_ray, N_samples, save_valid, after_march=None):
         lib = H.lib()
         if not rays.is_cuda:
             raise H.HipError("TensorBase.forward needs rays on the GPU (no CPU path in this build)")
@@ -625,21 +632,28 @@ class TensorBase(nn.Module):
         io.app_offset, io.app_count, io.val_count = ws.app_offset.data_ptr(), ws.app_count.data_ptr(), ws.val_count.data_ptr()
         io.counters = ws.counters.data_ptr()
         io.app_ray, io.app_xyz, io.app_w = ws.app_ray.data_ptr(), ws.app_xyz.data_ptr(), ws.app_w.data_ptr()
+        early = bool(save_valid and ws.binned_cfg is not None and self.early_sort and after_march is not None)
         if save_valid:
             io.val_idx, io.val_feat = ws.val_idx.data_ptr(), ws.val_feat.data_ptr()
+            if early:       # the forward places the density entries of the backward's binned scatter (TfMarchIO.ent_xyz)
+                io.ent_xyz, io.ent_offset = ws.ent_xyz.data_ptr(), ws.ent_offset.data_ptr()
+                if self._sort_stream is not None and not torch.cuda.is_current_stream_capturing():
+                    # a forward whose backward never ran may have left its sorts in flight on this workspace
+                    torch.cuda.current_stream().wait_stream(self._sort_stream)
         if ws.debug:
             ws.dbg_app.zero_()
             io.dbg_bbox_bits, io.dbg_valid_bits = ws.dbg_bbox.data_ptr(), ws.dbg_valid.data_ptr()
             io.dbg_app_bits = ws.dbg_app.data_ptr()
         self._timed("tf_march_forward", lib.tf_march_forward, C.byref(field), C.byref(io), st)
+        sorted_on = after_march(ws, field, shade) if early else None
         self._timed("tf_shade_forward", lib.tf_shade_forward, C.byref(shade), rays.data_ptr(), int(bool(ndc_ray)),
                     ws.counters.data_ptr(), ws.seg_cap, ws.app_ray.data_ptr(), ws.app_xyz.data_ptr(),
-                    ws.rgb.data_ptr(), st)
+                    ws.rgb.data_ptr(), self.shade_wgs_beside_sort if sorted_on is not None else 0, st)
         self._timed("tf_composite_forward", lib.tf_composite_forward, R, ws.app_offset.data_ptr(),
                     ws.app_count.data_ptr(), ws.app_w.data_ptr(), ws.rgb.data_ptr(), ws.acc.data_ptr(), int(use_bg),
                     out_rgb.data_ptr(), ws.rgb_pre.data_ptr() if save_valid else None, st)
         ctx = dict(ws=ws, rgb_map=out_rgb, depth=out_depth, rays=rays, field=field, shade=shade, io=io, keep=(keep, den_masks, app_masks, jitter, ztab),
-                   use_bg=use_bg, ndc=bool(ndc_ray))
+                   use_bg=use_bg, ndc=bool(ndc_ray), sorted_on=sorted_on)
         self.last = ctx
         return ctx
 

@@ -110,6 +110,12 @@ typedef struct TfMarchIO {
     uint64_t* dbg_bbox_bits;
     uint64_t* dbg_valid_bits;
     uint64_t* dbg_app_bits;   /* must be zeroed by the caller */
+    /* training with the binned scatter (optional, with save_valid): the forward already reserves the ray's block of
+     * the density entry list (counter slot 3) and writes the entries' normalised coordinates, so that the entries can
+     * be sorted (tf_binned_scatter stage 1) while the shading kernels run; tf_march_backward then only fills in
+     * dL/df at ent_offset[r] + k. */
+    float* ent_xyz;        /* (cap,3) or NULL */
+    int* ent_offset;       /* (R) first density entry of the ray */
 } TfMarchIO;
 
 /* One positional-encoding block of the MLP input (mlp.py:8-13, 41-66, 84-103, 126-153). */
@@ -181,9 +187,11 @@ int tf_march_forward(const TfField* field, const TfMarchIO* io, tf_stream_t stre
 
 /* compute_appfeature + renderModule on the packed app list: tensoRF.py:230-263, 388-415; mlp.py.
  * counters/seg_cap describe the sharded packed list; rays gives view directions (normalised when ndc,
- * tensorBase.py:343); rgb_out is (capacity,3), written at the packed positions. */
+ * tensorBase.py:343); rgb_out is (capacity,3), written at the packed positions.  The kernel is persistent (tiles
+ * are handed out by a ticket): max_workgroups (0 = all 512 slots, two per CU) leaves CU slots free for kernels the
+ * caller runs next to it on another stream (the training step's early sorts of the binned scatter). */
 int tf_shade_forward(const TfShade* shade, const float* rays, int ndc, const int* counters, int seg_cap,
-                     const int* app_ray, const float* app_xyz, float* rgb_out, tf_stream_t stream);
+                     const int* app_ray, const float* app_xyz, float* rgb_out, int max_workgroups, tf_stream_t stream);
 
 /* rgb_map = sum w*rgb (+ 1-acc when bg) clamped to [0,1]: tensorBase.py:378-384.  rgb_pre (optional)
  * receives the pre-clamp value, which the backward needs for the clamp mask. */
@@ -203,7 +211,8 @@ int tf_march_backward(const TfField* field, const TfMarchIO* io, const float* gr
                       int white_bg, const float* rgb, float* grad_rgb, const TfFactorGrads* dgrads,
                       float* ent_xyz, float* ent_df, tf_stream_t stream);
 /* ent_xyz/ent_df != NULL: instead of scattering, the kernel appends one entry (normalised xyz, dL/df) per
- * density sample with a non-zero gradient to the sharded entry list (counter slot 3) for tf_binned_scatter. */
+ * density sample with a non-zero gradient to the sharded entry list (counter slot 3) for tf_binned_scatter.
+ * When io->ent_offset is set the forward has already placed the entries (TfMarchIO.ent_xyz): only ent_df is written. */
 
 /* Backward of the shading head + appearance lookup: recomputes the tile forward, then accumulates
  * gradients of w1,b1,w2,b2,w3,b3, basis and the appearance factors.  Gradient matrices use the
@@ -283,6 +292,9 @@ typedef struct TfBinJob {
     int* hist; int* offsets; int* cursor; int* chunk_off; int* binned;
     int nkeys;
     int hist_zeroed;          /* 1: the caller has zeroed hist[0..nkeys) on this stream (saves a launch) */
+    int stage;                /* 0: sort the entries by key, then scatter; 1: sort only (needs xyz and the counters, not
+                               * grad: can run as soon as the entry coordinates exist, on another stream); 2: scatter
+                               * only, the workspace holds the result of an earlier stage-1 call of the same job */
 } TfBinJob;
 #define TF_BIN_MAX_KEYS 262144  /* tf_binned_scatter returns hipErrorInvalidValue above this (the sort walks the keys in
                                  * LDS-sized ranges of 16384; ~1000^3 grids at 48 components stay below) */
