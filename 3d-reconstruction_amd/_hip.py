@@ -145,6 +145,7 @@ _SIGS = {
     "tf_bin_nkeys": [C.c_int, C.POINTER(C.c_int * 3), C.POINTER(C.c_int * 3), C.c_int, C.c_int],
     "tf_bin_keys_per_entry": [C.c_int, C.POINTER(C.c_int * 3)],
     "tf_binned_scatter": [C.POINTER(TfBinJob), _fp],
+    "tf_binned_sort_pair": [C.POINTER(TfBinJob), C.POINTER(TfBinJob), _fp],
     "tf_shade_backward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp,
                           C.POINTER(TfShadeGrads), _fp],
     "tf_adam_step": [C.POINTER(TfAdamJob), _fp],

@@ -66,7 +66,7 @@ def _bin_job(model, ws, part, factors, grid, stage, fgrads=None, grad=None, grad
     return j
 
 
-def _early_sort(model, ws, field, shade):
+def _early_sort(model, ws, field, shade, named):
     """Fork: both entry lists of the backward's binned scatter are complete once tf_march_forward has run (the
     appearance samples' coordinates, and — TfMarchIO.ent_xyz — the density samples'), so their counting sorts
     (three small, latency-bound kernels each) are issued on a second stream here and run next to the shading
@@ -79,20 +79,26 @@ def _early_sort(model, ws, field, shade):
     lib = H.lib()
     with torch.cuda.stream(side):
         st = _stream()
-        model._timed("tf_bin_sort_density", lib.tf_binned_scatter,
-                     C.byref(_bin_job(model, ws, "density", field.density, field.grid, 1)), st)
-        model._timed("tf_bin_sort_app", lib.tf_binned_scatter,
+        model._timed("tf_binned_sort_pair", lib.tf_binned_sort_pair,
+                     C.byref(_bin_job(model, ws, "density", field.density, field.grid, 1)),
                      C.byref(_bin_job(model, ws, "app", shade.app, field.grid, 1)), st)
-    return side
+        # the step's (zero-filled) gradient buffer is produced here as well: 70 MB of fill off the main stream
+        bufs = _grad_buffers(named, 0)
+        bufs[1].record_stream(main)
+    return side, bufs
 
 
 class _RenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, rays, mask, white_bg, is_train, ndc_ray, N_samples, names, *params):
         ctx.set_materialize_grads(False)     # no zero-filled gradients for the two non-differentiable results
+        named_fwd = list(zip(names, params))
         c = model._run_forward(rays, mask, white_bg, is_train, ndc_ray, N_samples, save_valid=True,
-                               after_march=lambda ws, field, shade: _early_sort(model, ws, field, shade))
+                               after_march=lambda ws, field, shade: _early_sort(model, ws, field, shade, named_fwd))
         ws = c['ws']
+        ctx.early_bufs = None
+        if c.get('sorted_on') is not None:      # (second stream, gradient buffers): the buffers travel on ctx only —
+            c['sorted_on'], ctx.early_bufs = c['sorted_on']   # a second owner (model.last) would make autograd copy them
         ctx.model, ctx.c, ctx.names = model, c, names
         ctx.versions = [p._version for p in params]
         ctx.params = params
@@ -115,7 +121,12 @@ class _RenderFn(torch.autograd.Function):
         named = list(zip(names, ctx.params))
         binned = ws.binned_cfg is not None
         n_rep = 0 if binned else N_REP
-        grads, flat, offs, grad_len, line_len = _grad_buffers(named, n_rep)
+        presorted = c.get('sorted_on') is not None
+        if presorted:       # made on the second stream during the forward (_early_sort); usable after the join below
+            grads, flat, offs, grad_len, line_len = ctx.early_bufs
+            ctx.early_bufs = None
+        else:
+            grads, flat, offs, grad_len, line_len = _grad_buffers(named, n_rep)
         model.grad_flat = flat[:grad_len]   # every gradient of this step, one contiguous buffer (parallel.py)
         if getattr(model, "grad_layout", None) is None or model.grad_layout[0] != offs:
             model.grad_layout = (offs, grad_len)     # name -> offset (floats): parallel.gradient_support
@@ -133,7 +144,6 @@ class _RenderFn(torch.autograd.Function):
                 if not cp:
                     fg.plane[i] = grads[f'{kind}_plane.{i}'].data_ptr()
                 fg.line[i] = rep0 + 4 * offs[f'{kind}_line.{i}']
-        presorted = c.get('sorted_on') is not None
         def bin_job(factors, fgrads, grad, grad_ld, part):
             j = _bin_job(model, ws, part, factors, c['field'].grid, 2 if presorted else 0, fgrads, grad, grad_ld)
             model._timed("tf_binned_scatter_" + part, lib.tf_binned_scatter, C.byref(j), st)

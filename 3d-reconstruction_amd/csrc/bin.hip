@@ -93,6 +93,15 @@ __device__ __forceinline__ void sample_keys(const KeyMap& K, const int grid[3], 
 // 1 / 2 / 4 / 8 / 16 slices -> count 23 / 15 / 12.5 / 15 / 22 us, fill 50 / 32 / 24 / 31 / 50 us; 1024 threads: no change)
 constexpr int kSortThreads = 256;
 constexpr int kSlices = 4;   // workgroups per entry shard in the count / fill passes
+constexpr int kSortWgs = TF_N_SHARDS * kSlices;   // workgroups per job in the count / fill passes
+
+// The sort kernels take up to two jobs per launch (the training step sorts the density and the appearance entries
+// at the same time: three launches instead of six on the second stream); blockIdx selects the job.
+struct SortArgs {
+    TfBinJob J[2];
+    KeyMap K[2];
+    int csh[2];                // log2(chunk)
+};
 
 // (a kernel rather than hipMemsetAsync: the memset issued from this library was not replayed by a captured
 // hipGraph, which left the histogram un-zeroed on the second replay)
@@ -105,9 +114,12 @@ constexpr int kKeyRange = 16384;   // keys per LDS pass of the count / scan / fi
 // entries of shard g handled by slice k: local = k*256 + tid, += kSlices*256.  Jobs with more than kKeyRange keys
 // (grids beyond ~400^3 at 48 components) are counted in passes over key ranges; the entries of a workgroup are
 // few (cnt / kSlices), so re-deriving their keys per pass is cheap next to the LDS table work.
-__global__ __launch_bounds__(kSortThreads) void bin_count_kernel(const TfBinJob J, const KeyMap K) {
+__global__ __launch_bounds__(kSortThreads) void bin_count_kernel(const SortArgs A) {
     extern __shared__ int lh[];
-    const int g = blockIdx.x / kSlices, k = blockIdx.x % kSlices;
+    const int which = blockIdx.x / kSortWgs, bid = blockIdx.x % kSortWgs;
+    const TfBinJob& J = A.J[which];
+    const KeyMap& K = A.K[which];
+    const int g = bid / kSlices, k = bid % kSlices;
     const int cnt = J.counters[g * TF_SHARD_STRIDE + J.slot];
     for (int k0 = 0; k0 < K.nkeys; k0 += kKeyRange) {
         const int kn = min(kKeyRange, K.nkeys - k0);
@@ -135,8 +147,10 @@ __global__ __launch_bounds__(kSortThreads) void bin_count_kernel(const TfBinJob 
 // kernel a chain of memory latencies).  The kernel is kept SMALL on purpose (no per-thread register copy of the
 // histogram slice: 1024 threads at 128 VGPRs need a whole empty CU, and the training step runs this kernel next to
 // tf_shade_forward on a second stream).
-__global__ __launch_bounds__(1024, 8) void bin_scan_kernel(const TfBinJob J, int nkeys, int csh /* log2(J.chunk) */) {
+__global__ __launch_bounds__(1024, 8) void bin_scan_kernel(const SortArgs A) {
     extern __shared__ int sh[];                 // hist copy of the current key range, then its prefixes
+    const TfBinJob& J = A.J[blockIdx.x];
+    const int nkeys = A.K[blockIdx.x].nkeys, csh = A.csh[blockIdx.x];
     __shared__ int part[17], part2[17];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // item table: work item -> key (chunk index = item - chunk_off[key]); lives behind chunk_off[]
@@ -235,9 +249,12 @@ __global__ __launch_bounds__(1024, 8) void bin_scan_kernel(const TfBinJob J, int
     }
 }
 
-__global__ __launch_bounds__(kSortThreads) void bin_fill_kernel(const TfBinJob J, const KeyMap K) {
+__global__ __launch_bounds__(kSortThreads) void bin_fill_kernel(const SortArgs A) {
     extern __shared__ int lh[];  // per key: this workgroup's count, then its running write position in `binned`
-    const int g = blockIdx.x / kSlices, k = blockIdx.x % kSlices;
+    const int which = blockIdx.x / kSortWgs, bid = blockIdx.x % kSortWgs;
+    const TfBinJob& J = A.J[which];
+    const KeyMap& K = A.K[which];
+    const int g = bid / kSlices, k = bid % kSlices;
     const int cnt = J.counters[g * TF_SHARD_STRIDE + J.slot];
     for (int k0 = 0; k0 < K.nkeys; k0 += kKeyRange) {     // key ranges, as in bin_count_kernel
         const int kn = min(kKeyRange, K.nkeys - k0);
@@ -496,15 +513,55 @@ int tf_bin_keys_per_entry(int model, const int n_comp[3]) {
     return make_keymap(grid1, n_comp, 8, 8, model == TF_MODEL_CP).keys_per_entry;
 }
 
+static bool job_shape_ok(const TfBinJob* job, KeyMap& K) {
+    K = make_keymap(job->grid, job->factors.n_comp, job->tile, job->bucket, job->model == TF_MODEL_CP);
+    if (K.nkeys != job->nkeys || K.nkeys > TF_BIN_MAX_KEYS) return false;
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    return pow2(job->tile) && pow2(job->bucket) && pow2(job->chunk);
+}
+
+// count -> scan -> fill for one or two jobs (three launches either way)
+static int launch_sort(const TfBinJob* const jobs[2], int n, hipStream_t st) {
+    SortArgs A;
+    int kr = 0;
+    for (int j = 0; j < n; ++j) {
+        if (!job_shape_ok(jobs[j], A.K[j])) return (int)hipErrorInvalidValue;
+        A.J[j] = *jobs[j];
+        A.csh[j] = 0;
+        while ((1 << A.csh[j]) < jobs[j]->chunk) ++A.csh[j];
+        const int r = A.K[j].nkeys < kKeyRange ? A.K[j].nkeys : kKeyRange;      // keys per LDS pass
+        kr = r > kr ? r : kr;
+        if (!jobs[j]->hist_zeroed)
+            hipLaunchKernelGGL(zero_ints_kernel, dim3((A.K[j].nkeys + 255) / 256), dim3(256), 0, st, jobs[j]->hist, A.K[j].nkeys);
+    }
+    if (n == 1) {
+        A.J[1] = A.J[0];
+        A.K[1] = A.K[0];
+        A.csh[1] = A.csh[0];
+    }
+    const size_t lds = sizeof(int) * (size_t)kr;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(bin_count_kernel, dim3(n * kSortWgs), dim3(kSortThreads), lds, st, A);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(n), dim3(1024), lds, st, A);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(bin_fill_kernel, dim3(n * kSortWgs), dim3(kSortThreads), lds, st, A);
+    return TF_CHECK_LAUNCH();
+}
+
+int tf_binned_sort_pair(const TfBinJob* a, const TfBinJob* b, tf_stream_t stream) {
+    if (!a) return (int)hipErrorInvalidValue;
+    const TfBinJob* const jobs[2] = {a, b};
+    return launch_sort(jobs, b ? 2 : 1, (hipStream_t)stream);
+}
+
 int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
-    const KeyMap K = make_keymap(job->grid, job->factors.n_comp, job->tile, job->bucket, job->model == TF_MODEL_CP);
-    if (K.nkeys != job->nkeys || K.nkeys > TF_BIN_MAX_KEYS) return (int)hipErrorInvalidValue;
-    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    if (!pow2(job->tile) || !pow2(job->bucket) || !pow2(job->chunk)) return (int)hipErrorInvalidValue;
-    int csh = 0;
-    while ((1 << csh) < job->chunk) ++csh;
-    const int kr = K.nkeys < kKeyRange ? K.nkeys : kKeyRange;      // keys per LDS pass
+    KeyMap K;
+    if (!job_shape_ok(job, K)) return (int)hipErrorInvalidValue;
     int cmax = job->factors.n_comp[0];
     for (int i = 1; i < 3 && job->model != TF_MODEL_CP; ++i) cmax = job->factors.n_comp[i] > cmax ? job->factors.n_comp[i] : cmax;
     cmax = cmax > kCG ? kCG : cmax;
@@ -515,28 +572,15 @@ int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream) {
     if (sc_bytes > 150 * 1024) return (int)hipErrorInvalidValue;
     int per_cu = (int)((160 * 1024) / (sc_bytes + 512));
     per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
-    hipError_t e = hipSuccess;
     if (job->stage < 0 || job->stage > 2) return (int)hipErrorInvalidValue;
-    if (job->stage != 2) {      // sort: count -> scan -> fill
-        if (!job->hist_zeroed)
-            hipLaunchKernelGGL(zero_ints_kernel, dim3((K.nkeys + 255) / 256), dim3(256), 0, st, job->hist, K.nkeys);
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(sizeof(int) * kr));
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(bin_count_kernel, dim3(TF_N_SHARDS * kSlices), dim3(kSortThreads), sizeof(int) * kr, st, *job, K);
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(sizeof(int) * kr));
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), sizeof(int) * kr, st, *job, K.nkeys, csh);
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(sizeof(int) * kr));
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(bin_fill_kernel, dim3(TF_N_SHARDS * kSlices), dim3(kSortThreads), sizeof(int) * kr, st, *job, K);
-        if (job->stage == 1) return TF_CHECK_LAUNCH();
+    if (job->stage != 2) {
+        const TfBinJob* const jobs[2] = {job, nullptr};
+        const int rc = launch_sort(jobs, 1, st);
+        if (rc != 0 || job->stage == 1) return rc;
     }
     if (!job->grad) return (int)hipErrorInvalidValue;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)sc_bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)sc_bytes);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(256 * per_cu), dim3(256), sc_bytes, st, *job, K, ER, cmax);
     return TF_CHECK_LAUNCH();

@@ -303,6 +303,8 @@ typedef struct TfBinJob {
 int tf_bin_nkeys(int model, const int grid[3], const int n_comp[3], int tile, int bucket);
 int tf_bin_keys_per_entry(int model, const int n_comp[3]);
 int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream);
+/* The sort stage (stage 1) of two jobs at once — three launches instead of six; b may be NULL. */
+int tf_binned_sort_pair(const TfBinJob* a, const TfBinJob* b, tf_stream_t stream);
 
 /* dst[j] = sum_r rep[r*stride + j], j < numel: folds the line-gradient replicas. */
 int tf_reduce_replicas(const float* rep, int n_rep, int stride, int numel, float* dst, tf_stream_t stream);
