@@ -104,6 +104,20 @@ __global__ __launch_bounds__(64) void filter_rays_kernel(const TfField F, const 
     if (lane == 0) keep[r] = any;
 }
 
+// allrays[ray_idx], allrgbs[ray_idx] (train.py:297-298) in one launch: thread t moves float t of the 9 the batch row has
+__global__ __launch_bounds__(256) void gather_batch_kernel(const float* __restrict__ rays, const float* __restrict__ rgbs,
+                                                           const long long* __restrict__ ids, long long n_all, int n,
+                                                           float* __restrict__ rays_out, float* __restrict__ rgbs_out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * 9) return;
+    const int row = t / 9, c = t - row * 9;
+    long long src = ids[row];
+    if (src < 0) src += n_all;                       // torch indexing semantics for negative ids
+    if ((unsigned long long)src >= (unsigned long long)n_all) return;   // out of range: row left untouched
+    if (c < 6) rays_out[row * 6 + c] = rays[src * 6 + c];
+    else rgbs_out[row * 3 + (c - 6)] = rgbs[src * 3 + (c - 6)];
+}
+
 // Camera rays for a list (or a contiguous range) of pixels.  dataLoader/ray_utils.py:24-63
 // (pixel centre + 0.5, ((i - cx) / fx, +-(j - cy) / fy, +-1)), :66-87 (rays_d = dir @ c2w[:3,:3]^T, rays_o =
 // c2w[:3,3]), dataLoader/blender.py:59 (directions normalised before the rotation), ray_utils.py:90-107 (NDC).
@@ -157,6 +171,14 @@ __global__ __launch_bounds__(256) void generate_rays_kernel(const TfCamera cam, 
 }  // namespace
 
 extern "C" {
+
+int tf_gather_batch(const float* rays, const float* rgbs, long long n_all, const long long* ids, int n, float* rays_out,
+                    float* rgbs_out, tf_stream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(gather_batch_kernel, dim3((n * 9 + 255) / 256), dim3(256), 0, (hipStream_t)stream, rays, rgbs, ids, n_all, n,
+                       rays_out, rgbs_out);
+    return TF_CHECK_LAUNCH();
+}
 
 int tf_generate_rays(const TfCamera* cam, const long long* pixel_ids, long long first_pixel, int n, float* rays_out,
                      tf_stream_t stream) {

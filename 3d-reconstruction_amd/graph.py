@@ -74,7 +74,14 @@ class GraphedTrainStep:
         if ids is None:
             self.rays.copy_(rays, non_blocking=True)
             self.target.copy_(target, non_blocking=True)
-        else:       # gather the batch straight into the static buffers (allrays[ray_idx], train.py:298)
+        elif (rays.is_cuda and target.is_cuda and ids.is_cuda and ids.dtype == torch.int64 and rays.dtype == torch.float32
+              and target.dtype == torch.float32 and rays.is_contiguous() and target.is_contiguous()
+              and rays.shape[1:] == (6,) and target.shape[1:] == (3,) and target.shape[0] == rays.shape[0]
+              and ids.numel() == self.rays.shape[0]):
+            # allrays[ray_idx], allrgbs[ray_idx] (train.py:297-298) straight into the static buffers, one launch
+            H.check(H.lib().tf_gather_batch(rays.data_ptr(), target.data_ptr(), rays.shape[0], ids.contiguous().data_ptr(), ids.numel(),
+                                            self.rays.data_ptr(), self.target.data_ptr(), _stream()), "tf_gather_batch")
+        else:
             torch.index_select(rays, 0, ids, out=self.rays)
             torch.index_select(target, 0, ids, out=self.target)
         j = torch.rand(self.rays.shape[0], 1, pin_memory=True)   # same CPU-generator draw as the reference

@@ -263,6 +263,11 @@ typedef struct TfCamera {
     int ndc;
     float ndc_near;
 } TfCamera;
+/* The batch of a training step, `allrays[ray_idx]` and `allrgbs[ray_idx]` (train.py:297-298), gathered on the device
+ * in one launch: rays (n_all,6), rgbs (n_all,3), ids (n) int64 row numbers -> rays_out (n,6), rgbs_out (n,3).
+ * Negative ids count from the end; rows whose id is out of range are left untouched. */
+int tf_gather_batch(const float* rays, const float* rgbs, long long n_all, const long long* ids, int n, float* rays_out,
+                    float* rgbs_out, tf_stream_t stream);
 int tf_generate_rays(const TfCamera* cam, const long long* pixel_ids, long long first_pixel, int n, float* rays_out,
                      tf_stream_t stream);
 

@@ -163,3 +163,17 @@ def test_gradient_support_bounds_the_real_gradients(recon, scene):
     print(scene, f"cells = {cell_frac:.2%} of the gradient buffer ({live:.0%} of them non-zero in this one step)")
     # tightness: the outermost exchanged rows of the largest plane are within a few rows of real data
     print(scene, f"support = {frac:.2%} of the gradient buffer, {len(segs)} segments")
+
+
+def test_batch_gather_matches_indexing(recon):
+    """tf_gather_batch (GraphedTrainStep's staging) == allrays[ray_idx], allrgbs[ray_idx] (train.py:297-298)."""
+    import ctypes as C
+    from recon_amd import _hip as H
+    g = torch.Generator().manual_seed(5)
+    rays, rgbs = torch.randn(10007, 6, generator=g).to(DEV), torch.rand(10007, 3, generator=g).to(DEV)
+    ids = torch.randint(0, 10007, (4096,), generator=g).to(DEV)
+    ids[7] = -1
+    out_r, out_c = torch.zeros(4096, 6, device=DEV), torch.zeros(4096, 3, device=DEV)
+    H.check(H.lib().tf_gather_batch(rays.data_ptr(), rgbs.data_ptr(), 10007, ids.data_ptr(), 4096, out_r.data_ptr(),
+                                    out_c.data_ptr(), torch.cuda.current_stream().cuda_stream), "tf_gather_batch")
+    assert torch.equal(out_r, rays[ids]) and torch.equal(out_c, rgbs[ids])
