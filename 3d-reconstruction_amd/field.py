@@ -235,7 +235,10 @@ class TensorBase(nn.Module):
         self.t_stop = 0.0              # early ray termination threshold on transmittance (0 = off)
         self.count_samples = True      # False: forward() skips the num_valid_samples reduction (its 3rd result is then undefined)
         self.binned_scatter = True     # backward: counting-sorted LDS scatter (csrc/bin.hip) instead of per-tap atomics
-        self.early_sort = True         # sort the scatter's entries on a second stream right after the march kernel
+        # True: sort the binned scatter's entries on a second stream right after the march kernel, next to the shading
+        # kernel.  Pays when the sorts fit under the shading kernel (config 2: -8 % step time) and costs when they do not
+        # (C4 / C5: 7x the entries, +15-20 %): GraphedTrainStep switches it on from the measured sizes of its warm-up step
+        self.early_sort = False
         self._sort_stream = None
         # tf_shade_forward workgroups (of 512 CU slots) while the early sorts run next to it; the sort kernels need a CU
         # slot's LDS and registers (measured at config 2: 512 / 480 / 448 / 416 / 384 -> 0.939 / 0.936 / 0.930 / 0.928 / 0.929 ms per step)

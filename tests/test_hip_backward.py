@@ -13,16 +13,16 @@ GRAD_RTOL = 2e-4     # relative to the largest |gradient| of the tensor (float a
 
 # every case through the binned scatter (the default); three also through the direct scatter (per-tap atomics with
 # line replicas), the path jobs beyond the sort's key limit fall back to
-# ... and two with the sorts issued inside the backward (`early_sort = False`) instead of on the second stream
+# ... and every case again with the sorts issued on the second stream during the forward (`early_sort = True`)
 @pytest.mark.parametrize("name,binned", [(n, True) for n in GRAD_CASES] +
                          [("vm_cubic_train", False), ("vm_noncubic_relu", False), ("cp_train_mask", False)] +
-                         [("vm_cubic_train", "late"), ("cp_train_mask", "late")])
+                         [(n, "early") for n in GRAD_CASES])
 def test_gradients_match_reference(recon, name, binned):
     c = Case(name)
     dev = "cuda:0"
     model = build_model(recon, c, dev)
     model.binned_scatter = bool(binned)
-    model.early_sort = binned != "late"
+    model.early_sort = binned == "early"
     call = c.call
     torch.manual_seed(call["seed"])
     if call["ndc_ray"] and call["is_train"]:

@@ -11,6 +11,7 @@ import gc
 for name in sys.argv[1:] or ["C1_vm128", "C2_vm300", "C3_cp300_sh", "C3_cp300_mlp", "C4_ndc", "C5_tt640"]:
     model, rays, N, ndc, white = _scene(recon, name)
     model.lazy_sample_count = True
+    model.early_sort = bool(int(os.environ.get("EARLY", "0")))      # EARLY=1: sorts on a second stream during the forward
     gc.collect(); gc.freeze()
     target = torch.rand(rays.shape[0], 3, device=DEV)
     def ev():
