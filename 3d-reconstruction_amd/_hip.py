@@ -131,7 +131,7 @@ _SIGS = {
     "tf_generate_rays": [C.POINTER(TfCamera), _fp, C.c_longlong, C.c_int, _fp, _fp],
     "tf_march_forward": [C.POINTER(TfField), C.POINTER(TfMarchIO), _fp],
     "tf_shade_forward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, C.c_int, _fp],
-    "tf_composite_forward": [C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp],
+    "tf_composite_forward": [C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp, _fp, _fp],
     "tf_density_points": [C.POINTER(TfField), _fp, C.c_int, _fp, _fp],
     "tf_appfeature_points": [C.POINTER(TfShade), _fp, C.c_int, _fp, _fp],
     "tf_alpha_points": [C.POINTER(TfField), _fp, C.c_int, C.c_float, _fp, _fp],

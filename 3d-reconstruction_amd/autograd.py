@@ -105,7 +105,7 @@ class _RenderFn(torch.autograd.Function):
         rgb_map, depth = c.pop('rgb_map'), c.pop('depth')     # fresh tensors written by the kernels
         # the third result (`app_mask.sum()`, tensorBase.py:390) costs a reduction launch; callers that drop it
         # (graph.GraphedTrainStep) switch it off and get the un-summed per-shard counters' first entry instead
-        nvalid = ws.counters2d[:, 0].sum() if model.count_samples else ws.counters2d[0, 0]
+        nvalid = c['n_shaded'] if c['n_shaded'] is not None else ws.counters2d[0, 0]
         ctx.mark_non_differentiable(depth, nvalid)
         return rgb_map, depth, nvalid
 

@@ -304,7 +304,14 @@ __global__ __launch_bounds__(256) void composite_kernel(int n_rays, const int* _
                                                         const float* __restrict__ app_w,
                                                         const float* __restrict__ rgb, const float* __restrict__ acc,
                                                         int white_bg, float* __restrict__ rgb_map,
-                                                        float* __restrict__ rgb_pre) {
+                                                        float* __restrict__ rgb_pre,
+                                                        const int* __restrict__ counters,
+                                                        long long* __restrict__ n_shaded) {
+    if (n_shaded && blockIdx.x == 0 && threadIdx.x == 0) {     // num_valid_samples = app_mask.sum()  (tensorBase.py:390)
+        long long t = 0;
+        for (int g = 0; g < kShards; ++g) t += counters[g * kShardStride];
+        *n_shaded = t;
+    }
     const int r = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
     float c[3] = {0.f, 0.f, 0.f};
     if (r < n_rays) {
@@ -387,10 +394,10 @@ int tf_march_forward(const TfField* field, const TfMarchIO* io, tf_stream_t stre
 
 int tf_composite_forward(int n_rays, const int* app_offset, const int* app_count, const float* app_w,
                          const float* rgb, const float* acc, int white_bg, float* rgb_map, float* rgb_pre,
-                         tf_stream_t stream) {
+                         const int* counters, long long* n_shaded, tf_stream_t stream) {
     if (n_rays <= 0) return 0;
     hipLaunchKernelGGL(composite_kernel, dim3((n_rays + 31) / 32), dim3(256), 0, (hipStream_t)stream, n_rays,
-                       app_offset, app_count, app_w, rgb, acc, white_bg, rgb_map, rgb_pre);
+                       app_offset, app_count, app_w, rgb, acc, white_bg, rgb_map, rgb_pre, counters, n_shaded);
     return TF_CHECK_LAUNCH();
 }
 

@@ -631,6 +631,8 @@ class TensorBase(nn.Module):
         # the two per-ray results are written straight into fresh tensors (no copy out of the workspace)
         out_rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
         out_depth = torch.empty(R, dtype=torch.float32, device=dev)
+        # num_valid_samples (filled by the compositing kernel, which does not launch for an empty batch)
+        out_n = (torch.empty if R > 0 else torch.zeros)((), dtype=torch.int64, device=dev) if self.count_samples else None
         io.acc, io.depth = ws.acc.data_ptr(), out_depth.data_ptr()
         io.app_offset, io.app_count, io.val_count = ws.app_offset.data_ptr(), ws.app_count.data_ptr(), ws.val_count.data_ptr()
         io.counters = ws.counters.data_ptr()
@@ -654,9 +656,10 @@ class TensorBase(nn.Module):
                     ws.rgb.data_ptr(), self.shade_wgs_beside_sort if sorted_on is not None else 0, st)
         self._timed("tf_composite_forward", lib.tf_composite_forward, R, ws.app_offset.data_ptr(),
                     ws.app_count.data_ptr(), ws.app_w.data_ptr(), ws.rgb.data_ptr(), ws.acc.data_ptr(), int(use_bg),
-                    out_rgb.data_ptr(), ws.rgb_pre.data_ptr() if save_valid else None, st)
+                    out_rgb.data_ptr(), ws.rgb_pre.data_ptr() if save_valid else None, ws.counters.data_ptr(),
+                    H.ptr(out_n), st)
         ctx = dict(ws=ws, rgb_map=out_rgb, depth=out_depth, rays=rays, field=field, shade=shade, io=io, keep=(keep, den_masks, app_masks, jitter, ztab),
-                   use_bg=use_bg, ndc=bool(ndc_ray), sorted_on=sorted_on)
+                   use_bg=use_bg, ndc=bool(ndc_ray), sorted_on=sorted_on, n_shaded=out_n)
         self.last = ctx
         return ctx
 
@@ -667,9 +670,9 @@ class TensorBase(nn.Module):
             from .autograd import render_with_grad
             return render_with_grad(self, rays_chunk, mask, white_bg, is_train, ndc_ray, N_samples)
         ctx = self._run_forward(rays_chunk, mask, white_bg, is_train, ndc_ray, N_samples, save_valid=False)
-        ws = ctx['ws']
-        R = ws.R
-        num_valid = ws.counters2d[:, 0].sum()
+        # third result: app_mask.sum() (tensorBase.py:390), written by the compositing kernel; with count_samples off the
+        # caller gets the first shard's counter view instead (undefined value, no launch)
+        num_valid = ctx['n_shaded'] if ctx['n_shaded'] is not None else ctx['ws'].counters2d[0, 0]
         return ctx['rgb_map'], ctx['depth'], num_valid
 
     # ---- public feature hooks (used by compute_alpha in the reference) --------------------------

@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--host-inputs", action="store_true",
                     help="rays / targets stay in (pinned) host memory; every step gathers its batch on the CPU and copies "
                          "it over PCIe like train.py:297-298 (diagnostic: the PCIe-inclusive rate, never the headline)")
+    ap.add_argument("--profile-eager", action="store_true",
+                    help="eager modes: keep the per-kernel HIP events inside the timed region (for rocprofv3 runs)")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the one-launch tf_adam_step")
     return ap.parse_args()
 
@@ -254,7 +256,10 @@ def main():
     torch.manual_seed(1234 + rank)
     for i in range(args.warmup):
         step(i)
-    model.kernel_events = {}
+    # the timed region carries no instrumentation (HIP events between launches and the sample-count reductions cost
+    # ~40 us on a 0.2 ms eval step); per-kernel durations and sample statistics come from a separate pass below
+    timed_eager = not use_graph and not args.profile_eager
+    model.kernel_events = None if (use_graph or timed_eager) else {}
     torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()
@@ -264,7 +269,7 @@ def main():
     ctr_sum = torch.zeros(3, dtype=torch.int64, device=dev)
     for i in range(args.warmup, n_steps):
         step(i)
-        if not use_graph:
+        if args.profile_eager and not use_graph:
             ctr_sum += model.last["ws"].counters2d[:, :3].sum(0)
     host_issue = time.perf_counter() - t0        # host time to enqueue the timed steps (diagnostic: host- vs GPU-bound)
     torch.cuda.synchronize()
@@ -279,18 +284,21 @@ def main():
     events = model.kernel_events
     model.kernel_events = None
     eager_ms = None
-    if use_graph:
-        # the graph replays cannot carry HIP events, so the per-kernel durations come from an eager pass of the
-        # SAME step (same kernels, same batch shapes) run right here, bracketed launch by launch with events
-        opt, model.static_jitter = make_opt(False), None
+    n_e = args.steps
+    if use_graph or timed_eager:
+        # per-kernel durations: an eager pass of the SAME step (same kernels, same batch shapes) run right here,
+        # bracketed launch by launch with HIP events on the launch stream (graph replays cannot carry events)
+        if use_graph:
+            opt, model.static_jitter = make_opt(False), None
+        inst_step = train_step if args.mode == "train" else eval_step
         n_e = min(20, args.steps)
         for i in range(3):
-            train_step(i)
+            inst_step(i)
         model.kernel_events = {}
         torch.cuda.synchronize()
         te = time.perf_counter()
         for i in range(n_e):
-            train_step(args.warmup + i)
+            inst_step(args.warmup + i)
             ctr_sum += model.last["ws"].counters2d[:, :3].sum(0)
         torch.cuda.synchronize()
         eager_ms = (time.perf_counter() - te) / n_e * 1e3
@@ -300,8 +308,7 @@ def main():
     if rank == 0:
         k = args.steps
         c = ctr_sum.tolist()
-        if use_graph:
-            c = [v * k / min(20, k) for v in c]     # counters were summed over the eager pass only
+        c = [v * k / n_e for v in c]               # counters were summed over n_e instrumented steps
         stats = {"rays": B, "shaded": c[0] / k, "density": c[1] / k, "bbox": c[2] / k}
         cfg = dict(density_n_comp=model.density_n_comp, app_n_comp=model.app_n_comp, app_dim=model.app_dim,
                    featureC=model.featureC, in_c=model.renderModule.in_mlpC)

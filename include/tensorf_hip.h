@@ -194,10 +194,11 @@ int tf_shade_forward(const TfShade* shade, const float* rays, int ndc, const int
                      const int* app_ray, const float* app_xyz, float* rgb_out, int max_workgroups, tf_stream_t stream);
 
 /* rgb_map = sum w*rgb (+ 1-acc when bg) clamped to [0,1]: tensorBase.py:378-384.  rgb_pre (optional)
- * receives the pre-clamp value, which the backward needs for the clamp mask. */
+ * receives the pre-clamp value, which the backward needs for the clamp mask.  n_shaded (optional, with the sharded
+ * counters of the march kernel) receives num_valid_samples = app_mask.sum() (tensorBase.py:390) as one int64. */
 int tf_composite_forward(int n_rays, const int* app_offset, const int* app_count, const float* app_w,
                          const float* rgb, const float* acc, int white_bg, float* rgb_map, float* rgb_pre,
-                         tf_stream_t stream);
+                         const int* counters, long long* n_shaded, tf_stream_t stream);
 
 /* compute_densityfeature / compute_appfeature on an explicit point list (normalised coordinates),
  * the public hooks used by compute_alpha (tensorBase.py:298-318): out_f (S) / out_feat (S, app_dim). */
