@@ -12,6 +12,7 @@
 namespace {
 
 constexpr int kChunk = TF_ADAM_CHUNK;   // elements per workgroup
+static_assert(TF_ADAM_CHUNK == 8192, "the touched word holds 4 waves x 8 rounds of 256 floats");
 
 __global__ __launch_bounds__(256) void adam_kernel(const TfAdamJob J) {
     __shared__ float s_hyp[2];
@@ -43,17 +44,29 @@ __global__ __launch_bounds__(256) void adam_kernel(const TfAdamJob J) {
         pp -= step_size * mm / denom;
     };
     const long long n4 = n >> 2;
+    // `touched` (one word per workgroup): bit (8 * wave + round) is set once the 256 floats that wave handles in that
+    // round have seen a non-zero gradient.  While it is clear their moments are still the zeros they were created
+    // with, so only the gradient is read (1 of the 3 input streams); texels no sample ever reaches stay that way.
+    const int wave = tid >> 6;
+    const unsigned seen = J.touched ? J.touched[blockIdx.x] : 0xFFFFFFFFu;
+    unsigned fresh = 0;
+    int round = 0;
 #pragma unroll 2
-    for (long long i = tid; i < n4; i += 256) {
-        tf::float4_t mv = tf::ld4(m + 4 * i), vv = tf::ld4(v + 4 * i);
+    for (long long i = tid; i < n4; i += 256, ++round) {
+        const unsigned bit = 1u << (8 * wave + round);
+        tf::float4_t mv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+        if (seen & bit) {
+            mv = tf::ld4(m + 4 * i);
+            vv = tf::ld4(v + 4 * i);
+        }
         const tf::float4_t gv = tf::ld4(g + 4 * i);
         // Entries whose gradient and both moments are zero stay exactly as they are (m = v = 0, update 0 / (0 + eps)):
-        // a wave that holds only such entries — texels no sample has ever touched — neither reads the parameters nor
-        // writes anything back, which is exact and saves 4 of the 7 streams there.
+        // a wave that holds only such entries neither reads the parameters nor writes anything back, which is exact.
         bool live = false;
 #pragma unroll
         for (int e = 0; e < 4; ++e) live |= (gv[e] != 0.f) | (mv[e] != 0.f) | (vv[e] != 0.f);
         if (!__any(live)) continue;
+        fresh |= bit & ~seen;
         tf::float4_t pv = tf::ld4(p + 4 * i);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -65,6 +78,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const TfAdamJob J) {
         *reinterpret_cast<tf::float4_t*>(m + 4 * i) = mv;
         *reinterpret_cast<tf::float4_t*>(v + 4 * i) = vv;
     }
+    if (fresh && (tid & 63) == 0) atomicOr(J.touched + blockIdx.x, fresh);
     for (long long i = 4 * n4 + tid; i < n; i += 256) upd(p[i], g[i], m[i], v[i]);
     // every workgroup has read *step by now or will have before it arrives here: the last one to arrive advances the
     // count for the next launch and re-arms the arrival counter (no separate "step += 1" launch per update)

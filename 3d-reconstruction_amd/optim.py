@@ -52,15 +52,31 @@ class FusedAdam(torch.optim.Optimizer):
         v = torch.zeros(total, device=dev)
         self._step_dev = torch.zeros((), device=dev)           # completed updates
         self._arrivals = torch.zeros(1, dtype=torch.int32, device=dev)
+        # one word per kernel workgroup: which 256-float pieces have ever had a non-zero gradient (TfAdamJob.touched);
+        # the moments of the others are still zero and are not read
+        n_chunks = sum((p.numel() + H.ADAM_CHUNK - 1) // H.ADAM_CHUNK for _, p in ps)
+        self._touched = torch.zeros(n_chunks, dtype=torch.int32, device=dev)
         for (gi, p), o in zip(ps, offs):
             st = self.state[p]
-            st['step'] = self._step_dev
+            loaded = st.get('exp_avg'), st.get('exp_avg_sq'), st.get('step')      # state restored by load_state_dict
             st['exp_avg'] = torch.as_strided(m, p.size(), p.stride(), o)
             st['exp_avg_sq'] = torch.as_strided(v, p.size(), p.stride(), o)
+            if loaded[0] is not None and loaded[1] is not None:
+                st['exp_avg'].copy_(loaded[0])
+                st['exp_avg_sq'].copy_(loaded[1])
+                self._touched.fill_(-1)                        # moments of unknown history: read everything
+                if loaded[2] is not None:
+                    self._step_dev.fill_(float(loaded[2]))
+            st['step'] = self._step_dev
         self._flat = (m, v, offs, [id(p) for _, p in ps])
         self._lr_dev = torch.zeros(len(self.param_groups), device=dev)
         self._lr_pin = torch.zeros(len(self.param_groups), pin_memory=True)
         self._lr_host = None
+
+    def load_state_dict(self, state_dict):
+        """Moments restored from a checkpoint replace the flat buffers' views; fold them back in on the next step."""
+        super().load_state_dict(state_dict)
+        self._flat = None
 
     def sync_lr(self):
         """Uploads the groups' learning rates when they changed on the host (train.py:391-392 decays them every
@@ -92,6 +108,7 @@ class FusedAdam(torch.optim.Optimizer):
         one_launch = len(ps) <= H.ADAM_MAX_SEG       # then the kernel advances the step count itself
         g0 = self.param_groups[0]
         lib, st = H.lib(), _stream()
+        chunk0 = 0
         for s0 in range(0, len(ps), H.ADAM_MAX_SEG):
             job = H.TfAdamJob()
             part = ps[s0:s0 + H.ADAM_MAX_SEG]
@@ -112,6 +129,8 @@ class FusedAdam(torch.optim.Optimizer):
             job.beta1, job.beta2, job.eps = g0['betas'][0], g0['betas'][1], g0['eps']
             if one_launch:
                 job.step_rw, job.arrivals = self._step_dev.data_ptr(), self._arrivals.data_ptr()
+            job.touched = self._touched.data_ptr() + 4 * chunk0
+            chunk0 += run
             H.check(lib.tf_adam_step(C.byref(job), st), "tf_adam_step")
         if not one_launch:
             self._step_dev += 1

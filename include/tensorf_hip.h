@@ -370,6 +370,9 @@ typedef struct TfAdamJob {
     double beta1, beta2, eps;
     float* step_rw;           /* == step, writable (used with arrivals) */
     unsigned int* arrivals;   /* NULL, or a zeroed device counter */
+    unsigned int* touched;    /* NULL, or one word per workgroup (chunk of TF_ADAM_CHUNK elements), zero when the
+                               * moments are created: bit set = that 256-float piece has had a non-zero gradient;
+                               * pieces whose bit is clear have zero moments, which are then not read */
 } TfAdamJob;
 int tf_adam_step(const TfAdamJob* job, tf_stream_t stream);
 

@@ -213,3 +213,42 @@ def test_graphed_fused_adam_follows_lr_schedule(recon):
         assert not graphed or gs.graph is not None
         finals.append({k: v.detach().clone() for k, v in model.state_dict().items()})
     _same_trajectory(finals, init, losses)
+
+
+@pytest.mark.gpu
+def test_fused_adam_untouched_regions_and_state_restore(recon):
+    """Regions whose gradient stays zero for a while (texels no sample reaches yet): FusedAdam skips their moments
+    (TfAdamJob.touched) and must still take torch.optim.Adam's steps once gradient arrives; then a state_dict round
+    trip into a fresh optimizer continues the same trajectory."""
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    shape = (1, 16, 97, 53)
+    pa = torch.nn.Parameter(recon.channel_last_param(torch.randn(*shape)).data.to(dev))
+    pb = torch.nn.Parameter(pa.detach().clone())
+    assert pa.stride() == pb.stride()
+    oa = torch.optim.Adam([pa], lr=0.02, betas=(0.9, 0.99))
+    ob = recon.FusedAdam([pb], lr=0.02, betas=(0.9, 0.99))
+    g = torch.Generator().manual_seed(1)
+
+    def grads(it):
+        gr = torch.randn(*shape, generator=g).to(dev)
+        live = torch.zeros(97, dtype=torch.bool, device=dev)
+        live[: 10 + 20 * it] = True                     # rows (contiguous in the channel-last storage) wake up over time
+        return gr * live[None, None, :, None]
+
+    def run(n, oa, ob, first):
+        for it in range(first, first + n):
+            gr = grads(it)
+            pa.grad = torch.empty_like(pa).copy_(gr)
+            pb.grad = torch.empty_like(pb).copy_(gr)
+            oa.step()
+            ob.step()
+    run(4, oa, ob, 0)
+    assert (pa - pb).abs().max().item() <= 2e-6
+    assert 0 < int((ob._touched != 0).sum()) and int((ob._touched == -1).sum()) < ob._touched.numel()
+    ob2 = recon.FusedAdam([pb], lr=0.02, betas=(0.9, 0.99))
+    ob2.load_state_dict(ob.state_dict())
+    run(3, oa, ob2, 4)
+    assert (pa - pb).abs().max().item() <= 3e-6
+    assert float(ob2.state[pb]['step']) == 7
+    assert (oa.state[pa]['exp_avg'] - ob2.state[pb]['exp_avg']).abs().max().item() <= 2e-6 * oa.state[pa]['exp_avg'].abs().max().item()
