@@ -107,6 +107,40 @@ __host__ __device__ inline size_t wslab_floats(const TfShade& S) {
     return (size_t)(FT * FT + FT * kt1 + NB * ktB) * 256;
 }
 
+// The packed sample list is cut EVENLY over the persistent workgroups: workgroup w owns samples [w q, (w+1) q) of the
+// shards' concatenation, q = max(64, ceil(S / workgroups)), and walks them in chunks of <= 64.  (Whole 64-sample tiles
+// dealt round-robin leave most workgroups one tile short of the busiest: at config 2, 1281-1288 tiles on 256
+// workgroups are 6 rounds instead of 5.03.)  A chunk may straddle a shard boundary, so it has two pieces.
+struct Chunk {
+    int s0, n0, s1, n1;      // packed positions / lengths of the two pieces (n1 may be 0)
+    __device__ __forceinline__ int n() const { return n0 + n1; }
+    __device__ __forceinline__ size_t at(int k) const { return k < n0 ? (size_t)s0 + k : (size_t)s1 + (k - n0); }
+};
+__host__ __device__ inline int samples_per_wg(int total, int n_wg) {
+    const int q = (total + n_wg - 1) / n_wg;
+    return q < M ? M : q;
+}
+// spre: exclusive prefix of the shards' sample counts (TF_N_SHARDS + 1 entries); v in [0, v_end)
+__device__ __forceinline__ bool locate_chunk(const TileSrc& src, const int* spre, int v, int v_end, Chunk& c) {
+    c.s0 = c.n0 = c.s1 = c.n1 = 0;
+    if (v >= v_end) return false;
+    int g = 0;
+#pragma unroll
+    for (int k = 1; k < TF_N_SHARDS; ++k) g = spre[k] <= v ? k : g;      // last shard starting at or before v
+    const int want = min(M, v_end - v);
+    c.s0 = g * src.seg_cap + (v - spre[g]);
+    c.n0 = min(want, spre[g + 1] - v);
+    if (c.n0 < want) {
+        int g2 = g + 1;
+        while (g2 < TF_N_SHARDS && spre[g2 + 1] == spre[g2]) ++g2;       // skip empty shards
+        if (g2 < TF_N_SHARDS) {
+            c.s1 = g2 * src.seg_cap;
+            c.n1 = min(want - c.n0, spre[g2 + 1] - spre[g2]);
+        }
+    }
+    return true;
+}
+
 // FT = feature_c/16 hidden feature tiles (4 or 8), NB = ceil(app_dim/16) (1..2), KT1 = upper bound of the first
 // layer's k tiles kept in registers.  512 threads = 8 waves = 2 per SIMD (256 registers each, no scratch:
 // kernels that spill cannot be replayed from a hipGraph on this stack).
@@ -155,27 +189,27 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
 #pragma unroll
         for (int i = 0; i < NB; ++i) aB[k][i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (src.counters) {
-        if (tid == 0) {
-            int run = 0;
-            for (int g = 0; g < TF_N_SHARDS; ++g) {
-                pre[g] = run;
-                run += (src.counters[g * TF_SHARD_STRIDE] + M - 1) / M;
-            }
-            pre[TF_N_SHARDS] = run;
+    if (tid == 0) {
+        int run = 0;
+        for (int g = 0; g < TF_N_SHARDS; ++g) {
+            pre[g] = run;
+            run += src.counters[g * TF_SHARD_STRIDE];
         }
-        __syncthreads();
+        pre[TF_N_SHARDS] = run;
     }
+    __syncthreads();
+    const int q_wg = samples_per_wg(pre[TF_N_SHARDS], (int)gridDim.x);
+    const int v_end = min(pre[TF_N_SHARDS], ((int)blockIdx.x + 1) * q_wg);
 
-    // per-sample tile info of thread tid < 64, loaded for the NEXT tile while the current one is processed
+    // per-sample tile info of thread tid < 64, loaded for the NEXT chunk while the current one is processed
     int nx_ray = 0;
     float nx_x[3] = {0.f, 0.f, 0.f}, nx_v[3] = {0.f, 0.f, 0.f};
-    auto fetch_info = [&](int s0_, int n_, int tid) {   // tid passed in: the tile loop hands its opaque copy
+    auto fetch_info = [&](const Chunk& ck, int tid) {   // tid passed in: the tile loop hands its opaque copy
         nx_ray = 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) nx_x[a] = nx_v[a] = 0.f;
-        if (tid < n_) {
-            const size_t s = (size_t)s0_ + tid;
+        if (tid < ck.n()) {
+            const size_t s = ck.at(tid);
             nx_x[0] = src.app_xyz[s * 3]; nx_x[1] = src.app_xyz[s * 3 + 1]; nx_x[2] = src.app_xyz[s * 3 + 2];
             nx_ray = src.app_ray[s];
             const float* rp = src.rays + (size_t)nx_ray * 6 + 3;
@@ -183,14 +217,16 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         }
     };
     {
-        int s1, n1;
-        if (tid < M && locate_tile(src, pre, (int)blockIdx.x, s1, n1)) fetch_info(s1, n1, tid);
+        Chunk c1;
+        if (tid < M && locate_chunk(src, pre, (int)blockIdx.x * q_wg, v_end, c1)) fetch_info(c1, tid);
     }
 
     TF_T0();
-    for (int t = blockIdx.x;; t += gridDim.x) {
-        int s0, n;
-        if (!locate_tile(src, pre, t, s0, n)) break;
+    for (int v = (int)blockIdx.x * q_wg;;) {
+        Chunk ck;
+        if (!locate_chunk(src, pre, v, v_end, ck)) break;
+        const int n = ck.n();
+        v += n;
         // Thread coordinates are re-derived per tile from an opaque copy of the thread id: otherwise the compiler
         // hoists every phase's per-thread addresses out of the tile loop and runs out of registers (scratch
         // spills, which also break hipGraph replay on this stack).
@@ -218,8 +254,8 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         }
         lds_barrier();
         {
-            int s1, n1;
-            if (tid < M && locate_tile(src, pre, t + (int)gridDim.x, s1, n1)) fetch_info(s1, n1, tid);
+            Chunk c1;
+            if (tid < M && locate_chunk(src, pre, v, v_end, c1)) fetch_info(c1, tid);
         }
 
         // ================= forward recompute =================
@@ -324,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                 float d = 0.f;
                 if (smp < n) {
                     const float c = 1.f / (1.f + expf(-(ov + S.b3[sub])));
-                    d = grad_rgb[((size_t)s0 + smp) * 3 + sub] * (c * (1.f - c));
+                    d = grad_rgb[ck.at(smp) * 3 + sub] * (c * (1.f - c));
                 }
                 dO[smp * 4 + sub] = d;
             }
@@ -488,7 +524,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         // hand dL/dV to the scatter stage (tf_binned_scatter for VM, app_direct_scatter_kernel otherwise)
         for (int smp = wave; smp < n; smp += NW)
             for (int c = lane; c < S.n_app_total; c += 64)
-                G.dv_out[((size_t)s0 + smp) * S.n_app_total + c] = V[smp * L.sv + c];
+                G.dv_out[ck.at(smp) * S.n_app_total + c] = V[smp * L.sv + c];
         first = false;
         lds_barrier();
         TF_MARK(7);
@@ -532,7 +568,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
 }
 
 // Sums the workgroups' weight-gradient slabs (fragment order) into the row-major gradient matrices.  Workgroup b
-// wrote its slab iff it owned at least one tile, i.e. b < total tiles.  One workgroup per 16x16 tile (256 floats
+// wrote its slab iff it owned samples, i.e. b * samples_per_wg < total.  One workgroup per 16x16 tile (256 floats
 // = 64 float4 columns): thread (group g = tid>>6, lane) adds the slabs b = g, g+4, ... with 16-B loads, the four
 // groups meet in LDS.
 __global__ __launch_bounds__(256) void wslab_reduce_kernel(const TfShade S, const int* __restrict__ counters,
@@ -542,8 +578,9 @@ __global__ __launch_bounds__(256) void wslab_reduce_kernel(const TfShade S, cons
     const int tid = threadIdx.x, grp = tid >> 6, lane = tid & 63;
     if (tid == 0) {
         int run = 0;
-        for (int g = 0; g < TF_N_SHARDS; ++g) run += (counters[g * TF_SHARD_STRIDE] + M - 1) / M;
-        s_active = run < n_wg ? run : n_wg;
+        for (int g = 0; g < TF_N_SHARDS; ++g) run += counters[g * TF_SHARD_STRIDE];
+        const int q = samples_per_wg(run, n_wg);      // workgroup b of shade_backward owned samples iff b q < total
+        s_active = (run + q - 1) / q;
     }
     __syncthreads();
     const int active = s_active;
