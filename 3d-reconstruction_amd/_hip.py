@@ -90,7 +90,7 @@ class TfPackItem(C.Structure):
 
 
 class TfPackJob(C.Structure):
-    _fields_ = [("n", C.c_int), ("pad_", C.c_int), ("item", TfPackItem * PACK_MAX)]
+    _fields_ = [("n", C.c_int), ("n_zero", C.c_int), ("item", TfPackItem * PACK_MAX), ("zero", _fp)]
 
 
 class TfRegJob(C.Structure):

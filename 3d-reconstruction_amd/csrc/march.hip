@@ -259,6 +259,10 @@ __global__ __launch_bounds__(256) void pack_matrix_t_kernel(const float* __restr
 // several pack jobs in one launch (blockIdx.y = job): the training step refreshes 5 padded / transposed weight
 // copies after every optimizer step
 __global__ __launch_bounds__(256) void pack_matrices_kernel(const TfPackJob J) {
+    if ((int)blockIdx.y == J.n) {      // extra row of workgroups: the forward's zero block rides along
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < J.n_zero; i += gridDim.x * blockDim.x) J.zero[i] = 0;
+        return;
+    }
     const TfPackItem& P = J.item[blockIdx.y];
     const int kp = (P.cols + 15) & ~15, total = P.rows_pad * kp;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -373,7 +377,9 @@ int tf_pack_matrices(const TfPackJob* job, tf_stream_t stream) {
         const int total = job->item[k].rows_pad * ((job->item[k].cols + 15) & ~15);
         most = total > most ? total : most;
     }
-    hipLaunchKernelGGL(pack_matrices_kernel, dim3((most + 255) / 256, job->n), dim3(256), 0, (hipStream_t)stream, *job);
+    const bool zero = job->n_zero > 0 && job->zero;
+    hipLaunchKernelGGL(pack_matrices_kernel, dim3((most + 255) / 256, job->n + (zero ? 1 : 0)), dim3(256), 0,
+                       (hipStream_t)stream, *job);
     return TF_CHECK_LAUNCH();
 }
 

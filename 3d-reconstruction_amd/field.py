@@ -395,7 +395,7 @@ class TensorBase(nn.Module):
             f.alpha_cells = None
         return f
 
-    def _packed_many(self, reqs):
+    def _packed_many(self, reqs, zero=None):
         """Zero-padded copies [rows_pad][kpad16(cols)] of weight matrices (or their transposes [kpad16(cols)][rows_pad]),
         refreshed when the source changed — all stale ones in ONE tf_pack_matrices launch.  reqs: (key, src, rows_pad,
         transpose)."""
@@ -415,10 +415,14 @@ class TensorBase(nn.Module):
             todo.append((src.detach().contiguous(), dst, rows, cols, rows_pad, transpose))
             self._pack_cache[key] = (tag, dst)
             out.append(dst)
+        self._zero_rode = False
         for k0 in range(0, len(todo), H.PACK_MAX):
             job = H.TfPackJob()
             part = todo[k0:k0 + H.PACK_MAX]
             job.n = len(part)
+            if zero is not None and k0 == 0:      # the forward's counter / histogram block is zeroed by this launch too
+                job.zero, job.n_zero = zero.data_ptr(), zero.numel()
+                self._zero_rode = True
             for it, (s_, dst, rows, cols, rows_pad, transpose) in zip(job.item, part):
                 it.src, it.dst, it.rows, it.cols, it.rows_pad, it.transpose = s_.data_ptr(), dst.data_ptr(), rows, cols, \
                     rows_pad, int(transpose)
@@ -451,7 +455,7 @@ class TensorBase(nn.Module):
             blocks.append((src, freqs, mv))
         return blocks, keep
 
-    def _shade_desc(self, app_masks, enc_mask, dev, train=False, pack=True):
+    def _shade_desc(self, app_masks, enc_mask, dev, train=False, pack=True, zero=None):
         """pack=False: dimensions only (size / support queries), no weight copies are made or refreshed."""
         s = H.TfShade()
         s.model = H.MODEL_CP if self._is_cp() else H.MODEL_VM
@@ -491,7 +495,7 @@ class TensorBase(nn.Module):
         reqs += [('w1', mlp[0].weight, self.featureC, False), ('w2', mlp[2].weight, self.featureC, False)]
         if train:     # the backward GEMMs dH1 = W2^T dZ2, dX = W1^T dZ1 read the transposes
             reqs += [('w1t', mlp[0].weight, self.featureC, True), ('w2t', mlp[2].weight, self.featureC, True)]
-        packed = self._packed_many(reqs)
+        packed = self._packed_many(reqs, zero)
         keep += packed
         s.basis, s.w1, s.w2 = packed[0].data_ptr(), packed[1].data_ptr(), packed[2].data_ptr()
         if train:
@@ -619,10 +623,15 @@ class TensorBase(nn.Module):
         use_bg = bool(white_bg or (is_train and bool(torch.rand((1,)) < 0.5)))
 
         field = self._field_desc(den_masks)
-        shade, keep = self._shade_desc(app_masks, enc_mask, dev, train=save_valid)
         ws = self._workspace(R, N, dev, save_valid)
+        if save_valid and self._sort_stream is not None and not torch.cuda.is_current_stream_capturing():
+            # a training forward whose backward never ran may have left its early sorts in flight on this workspace
+            torch.cuda.current_stream().wait_stream(self._sort_stream)
+        self._zero_rode = False
+        shade, keep = self._shade_desc(app_masks, enc_mask, dev, train=save_valid, zero=ws.zero_block)
         st = _stream()
-        ws.zero_block.zero_()
+        if not self._zero_rode:      # no weight copy was due (inference with unchanged weights): zero on its own
+            ws.zero_block.zero_()
 
         io = H.TfMarchIO()
         io.rays, io.n_rays, io.n_samples, io.ndc = rays.data_ptr(), R, N, int(bool(ndc_ray))
@@ -642,9 +651,6 @@ class TensorBase(nn.Module):
             io.val_idx, io.val_feat = ws.val_idx.data_ptr(), ws.val_feat.data_ptr()
             if early:       # the forward places the density entries of the backward's binned scatter (TfMarchIO.ent_xyz)
                 io.ent_xyz, io.ent_offset = ws.ent_xyz.data_ptr(), ws.ent_offset.data_ptr()
-                if self._sort_stream is not None and not torch.cuda.is_current_stream_capturing():
-                    # a forward whose backward never ran may have left its sorts in flight on this workspace
-                    torch.cuda.current_stream().wait_stream(self._sort_stream)
         if ws.debug:
             ws.dbg_app.zero_()
             io.dbg_bbox_bits, io.dbg_valid_bits = ws.dbg_bbox.data_ptr(), ws.dbg_valid.data_ptr()

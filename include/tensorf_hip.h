@@ -169,8 +169,9 @@ typedef struct TfPackItem {
 } TfPackItem;
 typedef struct TfPackJob {
     int n;
-    int pad_;
+    int n_zero;               /* > 0: the launch also zeroes `zero[0..n_zero)` (the forward's counter / histogram block) */
     TfPackItem item[TF_PACK_MAX];
+    int* zero;
 } TfPackJob;
 int tf_pack_matrices(const TfPackJob* job, tf_stream_t stream);
 
