@@ -241,7 +241,7 @@ class TensorBase(nn.Module):
         self.early_sort = False
         self._sort_stream = None
         # tf_shade_forward workgroups (of 512 CU slots) while the early sorts run next to it; the sort kernels need a CU
-        # slot's LDS and registers (measured at config 2: 512 / 480 / 448 / 416 / 384 -> 0.939 / 0.936 / 0.930 / 0.928 / 0.929 ms per step)
+        # slot's LDS and registers (measured at config 2, 432 ... 512 in steps of 16: 0.882 - 0.889 ms per step, flat within the run-to-run noise)
         self.shade_wgs_beside_sort = 448
         self.bin_tile, self.bin_bucket, self.bin_chunk = 8, 8, 512
         self._jitter_override = None   # tests: inject the stratified jitter instead of drawing it
