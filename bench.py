@@ -186,7 +186,10 @@ def main():
     from recon_amd import parallel
     model, rays, targets, n_samples, reso = build_scene(recon_amd, dev, args.grid, args.views)
     B = args.batch
-    n_steps = args.steps + args.warmup
+    # the graphed train step needs a few eager steps of its own before it is captured (GraphedTrainStep: warm-up,
+    # early-sort decision, capture): they are set-up, run before the W warm-up steps whatever W is
+    n_setup = 5 if (args.mode == "train" and not args.no_graph) else 0
+    n_steps = args.steps + args.warmup + n_setup
     g = torch.Generator().manual_seed(20211202)
     perm = torch.randperm(rays.shape[0], generator=g)
     need = B * world * n_steps
@@ -254,7 +257,7 @@ def main():
     gc.collect()
     gc.freeze()
     torch.manual_seed(1234 + rank)
-    for i in range(args.warmup):
+    for i in range(n_setup + args.warmup):
         step(i)
     # the timed region carries no instrumentation (HIP events between launches and the sample-count reductions cost
     # ~40 us on a 0.2 ms eval step); per-kernel durations and sample statistics come from a separate pass below
@@ -267,7 +270,7 @@ def main():
     t0 = time.perf_counter()
     stats = {"rays": 0, "bbox": 0, "density": 0, "shaded": 0}
     ctr_sum = torch.zeros(3, dtype=torch.int64, device=dev)
-    for i in range(args.warmup, n_steps):
+    for i in range(n_setup + args.warmup, n_steps):
         step(i)
         if args.profile_eager and not use_graph:
             ctr_sum += model.last["ws"].counters2d[:, :3].sum(0)
