@@ -188,7 +188,7 @@ def main():
     B = args.batch
     # the graphed train step needs a few eager steps of its own before it is captured (GraphedTrainStep: warm-up,
     # early-sort decision, capture): they are set-up, run before the W warm-up steps whatever W is
-    n_setup = 5 if (args.mode == "train" and not args.no_graph) else 0
+    n_setup = 5 if (args.mode == "train" and not args.no_graph) else 3      # eager modes: workspaces, weight copies
     n_steps = args.steps + args.warmup + n_setup
     g = torch.Generator().manual_seed(20211202)
     perm = torch.randperm(rays.shape[0], generator=g)
