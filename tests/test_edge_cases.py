@@ -177,3 +177,30 @@ def test_batch_gather_matches_indexing(recon):
     H.check(H.lib().tf_gather_batch(rays.data_ptr(), rgbs.data_ptr(), 10007, ids.data_ptr(), 4096, out_r.data_ptr(),
                                     out_c.data_ptr(), torch.cuda.current_stream().cuda_stream), "tf_gather_batch")
     assert torch.equal(out_r, rays[ids]) and torch.equal(out_c, rgbs[ids])
+
+
+@pytest.mark.parametrize("n_rays", [1, 3, 9, 70])
+def test_gradients_of_very_small_batches(recon, n_rays):
+    """A handful of rays: the eight entry shards hold few samples each, so the shading backward's 64-sample chunks
+    straddle shard boundaries (and skip empty shards).  Gradients against the oracle's autograd."""
+    c, model = _model(recon, "vm_cubic_train")
+    rays = c.rays.to(DEV)[: n_rays * 5 : 5].contiguous()
+    target = torch.rand(rays.shape[0], 3, generator=torch.Generator().manual_seed(n_rays)).to(DEV)
+    torch.manual_seed(7)
+    rgb, _, nv = model(rays, None, white_bg=True, is_train=True)
+    torch.mean((rgb - target) ** 2).backward()
+    cfg, params = oracle_of(model, DEV)
+    for p in params.values():
+        p.requires_grad_(True)
+    torch.manual_seed(7)
+    o_rgb, _, o_n = R.render_rays(cfg, params, rays, None, white_bg=True, is_train=True, n_samples=-1)
+    torch.mean((o_rgb - target) ** 2).backward()
+    assert int(nv) == int(o_n)
+    np.testing.assert_allclose(rgb.detach().cpu().numpy(), o_rgb.detach().cpu().numpy(), rtol=RTOL, atol=ATOL_RGB)
+    top = max(float(params[k].grad.abs().max()) for k, _ in model.named_parameters())
+    for k, p in model.named_parameters():
+        og = params[k].grad
+        if float(og.abs().max()) < 1e-6 * top:
+            continue
+        rel = (p.grad - og).norm().item() / og.norm().item()
+        assert rel <= 2e-3, (k, rel)
