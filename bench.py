@@ -330,6 +330,19 @@ def main():
                                        "tf_march_forward": "march_forward_kernel",
                                        "tf_march_backward": "march_backward_kernel"}.get(dom, dom))
         value = B * world * k / elapsed
+        # whole-step view against the HBM roofline: algorithmic bytes per ray of the forward, plus — in
+        # training — the taps re-read and the gradient taps written by the backward and the optimizer's 7 streams of
+        # every parameter, amortised over the batch
+        cd_, ca_ = sum(model.density_n_comp), sum(model.app_n_comp)
+        per = {kk: stats[kk] / B for kk in ("bbox", "density", "shaded")}
+        b_fwd = 40.0 + 32.0 * per["bbox"] + 24.0 * cd_ * per["density"] + 24.0 * ca_ * per["shaded"]
+        n_param = sum(p.numel() for p in model.parameters())
+        b_ray = b_fwd if args.mode != "train" else \
+            b_fwd + 2.0 * (24.0 * cd_ * per["density"] + 24.0 * ca_ * per["shaded"]) + 28.0 * n_param / B
+        step_hbm = {"algo_bytes_per_ray": b_ray, "achieved_GBps": b_ray * value / world / 1e9, "peak_GBps": HBM_PEAK_GBS,
+                    "frac": b_ray * value / world / 1e9 / HBM_PEAK_GBS,
+                    "note": "per GPU; the factor tensors are L2 / Infinity-Cache resident, so this is algorithmic traffic, "
+                            "not HBM traffic (see roofline.traffic for the dominant kernel's measured bytes)"}
         line = {
             "metric": f"rays/sec ({args.mode}), Lego 800^2 @ {args.grid}^3 grid",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": k, "warmup": args.warmup,
@@ -348,6 +361,7 @@ def main():
                        "inputs": "host, gathered on the CPU + H2D per step" if args.host_inputs else "resident in HBM",
                        "eager_ms_per_step": eager_ms, "host_issue_ms_per_step": host_issue / k * 1e3},
             "roofline": roof,
+            "step_hbm_roofline": step_hbm,
             "kernels": {n: {"avg_ms": round(v["avg_ms"], 5), "GBps": round(v["GBps"], 1),
                             "TFLOPps": round(v["TFLOPps"], 2)} for n, v in kt.items()},
         }
