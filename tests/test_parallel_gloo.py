@@ -112,6 +112,16 @@ def _worker(rank, world, port, q):
         dist.all_gather(parts, mine5)
         ok_cells = ok_cells and torch.allclose(flat3, sum(parts), atol=1e-6)
     ok_support = ok_support and ok_cells
+    # 6. evaluation: contiguous ray blocks per rank, whole image on every rank after one all-gather
+    g6 = torch.Generator().manual_seed(5)
+    rays6 = torch.randn(1001, 6, generator=g6)
+    fake = lambda r: (r[:, :3] * 2.0 + 1.0, r[:, 3] - r[:, 4])
+    rgb6, dep6 = parallel.render_sharded(fake, rays6)
+    mine6 = parallel.eval_blocks(1001, world)[rank]
+    part_rgb, _ = parallel.render_sharded(fake, rays6, gather=False)
+    ok_eval = torch.equal(rgb6, fake(rays6)[0]) and torch.equal(dep6, fake(rays6)[1]) and \
+        part_rgb.shape[0] == mine6[1] - mine6[0] and parallel.eval_blocks(1001, world) == [(0, 501), (501, 1001)]
+    ok_support = ok_support and ok_eval
     s = parallel.allreduce_scalar(torch.tensor(float(rank)))
     q.put((rank, ok_shard, ok_grad, ok_flat and ok_support, float(s)))
     dist.destroy_process_group()

@@ -83,6 +83,14 @@ def _worker(rank, world, port, q):
         dist.all_gather(both, digest)
         out["same_params"] = bool(torch.equal(both[0], both[1]))
         out["finite"] = all(bool(torch.isfinite(p).all()) for p in model.parameters())
+        # 3. sharded evaluation: every rank ends up with the image a single process renders
+        def render(block):
+            with torch.no_grad():
+                r = recon.OctreeRender_trilinear_fast(block, model, chunk=1024, N_samples=N, white_bg=True, device=dev)
+            return r[0], r[2]
+        rgb_all, dep_all = parallel.render_sharded(render, rays[:3001])
+        rgb_one, dep_one = render(rays[:3001])
+        out["eval_same"] = bool(torch.equal(rgb_all, rgb_one) and torch.equal(dep_all, dep_one))
     except Exception as e:      # report instead of hanging the peer
         import traceback
         out["error"] = traceback.format_exc()
@@ -110,6 +118,6 @@ def test_two_rank_train_step_on_one_gpu():
         assert "error" not in r, r["error"]
         assert r["cells"] is not None and r["cells"] < 0.6 and r["shaded"] > 2000 and r["grad_max"] > 0, r
         assert r["exchange_err"] <= 1e-6 * r["grad_max"], r
-        assert r["split"] and r["graphs"] and r["same_params"] and r["finite"], r
+        assert r["split"] and r["graphs"] and r["same_params"] and r["finite"] and r["eval_same"], r
         assert min(r["losses"][3:]) < r["losses"][0], r["losses"]
     print("cells exchanged: %.1f %% of the gradient buffer" % (100 * res[0]["cells"]))
