@@ -12,6 +12,10 @@ Data parallel (`world_size > 1`): the step is captured as TWO graphs — forward
 step — with the one gradient all-reduce (`parallel.allreduce_gradients`, RCCL) issued eagerly between the two
 replays on the same stream, so no collective is ever inside a capture.
 
+When the schedule replaces the alpha mask or the parameters (updateAlphaMask, shrink, upsample_volume_grid — the
+caller then assigns the rebuilt optimizer to `.opt`, as train.py:300-311 rebuilds it), the next `step` notices,
+runs one eager step and captures again.
+
 Restrictions (else use the eager path): fixed batch size / N_samples, `white_bg=True` (the random background
 draw of tensorBase.py:380 is a host decision per step).  Results of EARLIER eager training forwards of the same
 model (`rgb`, the loss) must not be alive when the step is captured: they keep autograd's AccumulateGrad nodes bound
@@ -40,6 +44,7 @@ class GraphedTrainStep:
         self.split = (dist.is_available() and dist.is_initialized() and
                       (dist.get_world_size() > 1 or parallel.FORCE_EXCHANGE)) if split is None else bool(split)
         self.graph_opt = None
+        self._captured_for = None
         self._early = early_sort
         # data parallel: d loss / d rgb is pre-divided by the world size and the ranks' gradients are summed, which
         # equals averaging them without a second pass over the gradient buffer (1 / 2^k scales exactly)
@@ -56,6 +61,12 @@ class GraphedTrainStep:
         # PyTorch's whole-network capture recipe: warm-up iterations and the capture run on the same side
         # stream, so the autograd AccumulateGrad nodes are bound to the stream that is later captured
         self._side = torch.cuda.Stream(device=dev)
+
+    def _signature(self):
+        """What a captured graph depends on besides the static buffers: the alpha mask object and the parameters'
+        storage (both are replaced, not updated in place, by the schedule steps of train.py:300-311, 403-425)."""
+        m = self.model
+        return (id(m.alphaMask), tuple(p.data_ptr() for p in m.parameters()), id(self.opt))
 
     def _fwd_bwd(self):
         model = self.model
@@ -99,6 +110,11 @@ class GraphedTrainStep:
         self._stage(rays, target, ids)
         if hasattr(self.opt, "sync_lr") and self.opt._lr_dev is not None:
             self.opt.sync_lr()                                    # FusedAdam: lr schedule follows the host values
+        if self.graph is not None and self._signature() != self._captured_for:
+            # the model changed under the graph (updateAlphaMask / shrink / upsample_volume_grid replace the mask and the
+            # parameters, train.py:300-311): the captured pointers are stale -> warm up and capture again
+            self.graph = self.graph_opt = None
+            self._warm = 1
         if self.graph is not None:
             self.graph.replay()
             if self.split:
@@ -126,6 +142,7 @@ class GraphedTrainStep:
                 self._early = None
             return self.loss
         torch.cuda.synchronize()
+        self._captured_for = self._signature()
         g = torch.cuda.CUDAGraph()
         if not self.split:
             with torch.cuda.graph(g, stream=self._side):

@@ -170,3 +170,39 @@ def test_fused_regularisers_match_the_eager_terms(recon, grid, den, app):
         p = dict(model.named_parameters())[n]
         assert p.grad.stride() == p.stride()
         assert (p.grad - 0.5 - ref_g[n]).abs().max().item() <= 1e-5 * scale + 1e-7, n
+
+
+@pytest.mark.gpu
+def test_graphed_step_recaptures_after_schedule_steps(recon):
+    """updateAlphaMask / upsample_volume_grid replace the mask and the parameters under a captured step
+    (train.py:300-311, 403-425): GraphedTrainStep notices, warms up and captures again instead of replaying stale
+    pointers; the caller hands it the rebuilt optimizer."""
+    from recon_amd import synthetic as S
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    aabb = torch.tensor(S.LEGO_AABB, device=dev)
+    args = S.lego_args(density_n_comp=(8, 8, 8), app_n_comp=(16, 16, 16))
+    model = recon.TensorVMSplit(args, aabb, [40, 40, 40], S.LEGO_NEAR_FAR, dev)
+    S.make_trained_like(model, recon.AlphaGridMask, mask_res=32, radius=0.7)
+    allrays = S.blender_rays(1)
+    rays = allrays[torch.randperm(allrays.shape[0], generator=torch.Generator().manual_seed(3))[:2048]].to(dev).contiguous()
+    target = torch.rand(2048, 3, generator=torch.Generator().manual_seed(4)).to(dev)
+    N = 150
+    opt = recon.FusedAdam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+    gs = recon.GraphedTrainStep(model, opt, 2048, N, warmup=1)
+    for _ in range(4):
+        l0 = float(gs.step(rays, target))
+    g0 = gs.graph
+    assert g0 is not None
+    model.updateAlphaMask((32, 32, 32))                      # new AlphaGridMask object
+    l1 = float(gs.step(rays, target))                        # eager warm-up in the new state
+    l2 = float(gs.step(rays, target))                        # captured again
+    assert gs.graph is not None and gs.graph is not g0
+    model.upsample_volume_grid([48, 48, 48])                 # new parameters -> new optimizer (train.py:300-311)
+    gs.opt = recon.FusedAdam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+    g1 = gs.graph
+    for _ in range(3):
+        l3 = float(gs.step(rays, target, None))
+    assert gs.graph is not None and gs.graph is not g1
+    assert all(np.isfinite(v) for v in (l0, l1, l2, l3))
+    assert all(torch.isfinite(p).all() for p in model.parameters())
