@@ -66,7 +66,8 @@ class GraphedTrainStep:
         """What a captured graph depends on besides the static buffers: the alpha mask object and the parameters'
         storage (both are replaced, not updated in place, by the schedule steps of train.py:300-311, 403-425)."""
         m = self.model
-        return (id(m.alphaMask), tuple(p.data_ptr() for p in m.parameters()), id(self.opt))
+        lists = [getattr(m, n) for n in ("density_plane", "density_line", "app_plane", "app_line") if hasattr(m, n)]
+        return (id(m.alphaMask), id(self.opt), tuple(id(p) for lst in lists for p in lst))     # cheap: runs every step
 
     def _fwd_bwd(self):
         model = self.model
