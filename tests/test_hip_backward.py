@@ -252,3 +252,22 @@ def test_fused_adam_untouched_regions_and_state_restore(recon):
     assert (pa - pb).abs().max().item() <= 3e-6
     assert float(ob2.state[pb]['step']) == 7
     assert (oa.state[pa]['exp_avg'] - ob2.state[pb]['exp_avg']).abs().max().item() <= 2e-6 * oa.state[pa]['exp_avg'].abs().max().item()
+
+
+@pytest.mark.gpu
+def test_graphed_step_with_ndc_rays(recon):
+    """Forward-facing configuration (BASELINE config 4) through the captured step: the NDC jitter is a device-side
+    draw (tensorBase.py:183-184), which must keep advancing under graph replay."""
+    c = Case("vm_ndc_train")
+    dev = "cuda:0"
+    model = build_model(recon, c, dev)
+    call = c.call
+    n = call["N_samples"] if call["N_samples"] > 0 else model.nSamples
+    opt = recon.FusedAdam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+    rays, target = c.rays.to(dev), torch.from_numpy(c.expect("grad/target")).to(dev)
+    gs = recon.GraphedTrainStep(model, opt, rays.shape[0], n, ndc_ray=True, warmup=2)
+    torch.manual_seed(0)
+    losses = [gs.step(rays, target).item() for _ in range(10)]
+    assert gs.graph is not None and all(np.isfinite(losses))
+    assert len(set(losses[3:])) == len(losses[3:]), losses      # every replay sees new jitter and new parameters
+    assert min(losses[5:]) < losses[0], losses
