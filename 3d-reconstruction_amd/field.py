@@ -245,6 +245,7 @@ class TensorBase(nn.Module):
         self.shade_wgs_beside_sort = 448
         self.bin_tile, self.bin_bucket, self.bin_chunk = 8, 8, 512
         self._jitter_override = None   # tests: inject the stratified jitter instead of drawing it
+        self._bg_override = None       # GraphedTrainStep: outcome of the random-background draw of tensorBase.py:380
         self.static_jitter = None      # graph capture: device tensor (R,) the harness refills before every replay
         self._debug_masks = False      # tests: also emit the bbox / valid bitmaps
         self._ws_cache = {}
@@ -620,7 +621,10 @@ class TensorBase(nn.Module):
 
         jitter, ztab = self._sampling_inputs(rays, is_train, ndc_ray, N)
         # random background draw happens after the sampling draw (models/tensorBase.py:380)
-        use_bg = bool(white_bg or (is_train and bool(torch.rand((1,)) < 0.5)))
+        if self._bg_override is not None:      # graph.GraphedTrainStep made the draw itself (one graph per outcome)
+            use_bg = bool(self._bg_override)
+        else:
+            use_bg = bool(white_bg or (is_train and bool(torch.rand((1,)) < 0.5)))
 
         field = self._field_desc(den_masks)
         ws = self._workspace(R, N, dev, save_valid)

@@ -16,8 +16,8 @@ When the schedule replaces the alpha mask or the parameters (updateAlphaMask, sh
 caller then assigns the rebuilt optimizer to `.opt`, as train.py:300-311 rebuilds it), the next `step` notices,
 runs one eager step and captures again.
 
-Restrictions (else use the eager path): fixed batch size / N_samples, `white_bg=True` (the random background
-draw of tensorBase.py:380 is a host decision per step).  Results of EARLIER eager training forwards of the same
+Restrictions (else use the eager path): fixed batch size / N_samples.  With `white_bg=False` the random background
+draw of tensorBase.py:380 stays a host decision per step: the step is captured once per outcome (single process only).  Results of EARLIER eager training forwards of the same
 model (`rgb`, the loss) must not be alive when the step is captured: they keep autograd's AccumulateGrad nodes bound
 to the stream they ran on, the capture would record a dependency on that stream and HIP fails in
 `hipStreamEndCapture` (torch warns "AccumulateGrad node's stream does not match")."""
@@ -38,7 +38,7 @@ class GraphedTrainStep:
     EARLY_SORT_LIMITS = (500_000, 170_000)
 
     def __init__(self, model, optimizer, batch, n_samples, mask=None, ndc_ray=False, warmup=3, split=None,
-                 early_sort='auto'):
+                 early_sort='auto', white_bg=True):
         self.model, self.opt = model, optimizer
         # split: capture backward and optimizer separately with the gradient all-reduce in between
         self.split = (dist.is_available() and dist.is_initialized() and
@@ -56,6 +56,15 @@ class GraphedTrainStep:
         self.loss = torch.zeros((), device=dev)
         self._grad_rgb = torch.zeros(batch, 3, device=dev)
         self.n_samples, self.mask, self.ndc = n_samples, mask, ndc_ray
+        # white_bg=False (datasets without a white background, e.g. llff.py:141): the reference adds the white
+        # background to a training batch with probability 1/2 (tensorBase.py:380) — a host decision per step, so the
+        # step is captured once per outcome and the draw (same generator, same position in the stream) picks the graph
+        self.white_bg = bool(white_bg)
+        if self.split and not self.white_bg:
+            raise NotImplementedError("GraphedTrainStep: random backgrounds (white_bg=False) are not combined with the "
+                                      "data-parallel split step yet; use the eager loop")
+        self._graphs = {}            # use_bg -> (graph, graph_opt)
+        self._bg = True
         self.graph = None
         self._warm = max(1, warmup)   # >= 1: the first eager step also caches host copies of the geometry
         # PyTorch's whole-network capture recipe: warm-up iterations and the capture run on the same side
@@ -73,7 +82,8 @@ class GraphedTrainStep:
         model = self.model
         keep, model.count_samples = model.count_samples, False     # nobody reads num_valid_samples here
         try:
-            rgb, _, _ = model(self.rays, self.mask, white_bg=True, is_train=True, ndc_ray=self.ndc, N_samples=self.n_samples)
+            rgb, _, _ = model(self.rays, self.mask, white_bg=self.white_bg, is_train=True, ndc_ray=self.ndc,
+                              N_samples=self.n_samples)
         finally:
             model.count_samples = keep
         # loss = mean((rgb - target)^2) (train.py:334) and d loss / d rgb in one launch instead of ~8 torch kernels
@@ -109,18 +119,29 @@ class GraphedTrainStep:
     def step(self, rays, target, ids=None):
         """One optimisation step on (rays, target) — or on rows `ids` of them; returns the (device) loss tensor."""
         self._stage(rays, target, ids)
+        # random-background draw of tensorBase.py:380, taken after the jitter draw like the reference's forward does
+        self._bg = True if self.white_bg else bool(torch.rand((1,)) < 0.5)
+        self.model._bg_override = self._bg
+        try:
+            return self._step()
+        finally:
+            self.model._bg_override = None
+
+    def _step(self):
         if hasattr(self.opt, "sync_lr") and self.opt._lr_dev is not None:
             self.opt.sync_lr()                                    # FusedAdam: lr schedule follows the host values
-        if self.graph is not None and self._signature() != self._captured_for:
+        if self._graphs and self._signature() != self._captured_for:
             # the model changed under the graph (updateAlphaMask / shrink / upsample_volume_grid replace the mask and the
             # parameters, train.py:300-311): the captured pointers are stale -> warm up and capture again
+            self._graphs = {}
             self.graph = self.graph_opt = None
             self._warm = 1
-        if self.graph is not None:
-            self.graph.replay()
+        hit = self._graphs.get(self._bg)
+        if hit is not None:
+            hit[0].replay()
             if self.split:
                 parallel.allreduce_gradients(self.model, average=False)      # on model.grad_flat: a static buffer of the graph's pool
-                self.graph_opt.replay()
+                hit[1].replay()
             return self.loss
         self.model.static_jitter = self.jitter
         cur = torch.cuda.current_stream()
@@ -144,20 +165,23 @@ class GraphedTrainStep:
             return self.loss
         torch.cuda.synchronize()
         self._captured_for = self._signature()
+        pool = next(iter(self._graphs.values()))[0].pool() if self._graphs else None     # one pool for all variants
         g = torch.cuda.CUDAGraph()
         if not self.split:
-            with torch.cuda.graph(g, stream=self._side):
+            with torch.cuda.graph(g, stream=self._side, pool=pool):
                 self._body()
+            self._graphs[self._bg] = (g, None)
             self.graph = g
             g.replay()                                            # capture only records; run this step now
             return self.loss
         # thread-local capture mode: the process group's helper threads (RCCL proxy / watchdog, gloo workers) may
         # make HIP calls of their own while this thread captures; they never touch the captured stream
-        with torch.cuda.graph(g, stream=self._side, capture_error_mode="thread_local"):
+        with torch.cuda.graph(g, stream=self._side, pool=pool, capture_error_mode="thread_local"):
             self._fwd_bwd()
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2, stream=self._side, pool=g.pool(), capture_error_mode="thread_local"):
             self.opt.step()
+        self._graphs[self._bg] = (g, g2)
         self.graph, self.graph_opt = g, g2
         g.replay()
         parallel.allreduce_gradients(self.model, average=False)

@@ -271,3 +271,35 @@ def test_graphed_step_with_ndc_rays(recon):
     assert gs.graph is not None and all(np.isfinite(losses))
     assert len(set(losses[3:])) == len(losses[3:]), losses      # every replay sees new jitter and new parameters
     assert min(losses[5:]) < losses[0], losses
+
+
+@pytest.mark.gpu
+def test_graphed_step_with_random_background(recon):
+    """white_bg=False: the reference adds the white background to a training batch with probability 1/2
+    (tensorBase.py:380).  The captured step keeps one graph per outcome and follows the same host draws as the eager loop."""
+    c = Case("vm_cubic_train")
+    dev = "cuda:0"
+    rays, target = c.rays.to(dev), torch.from_numpy(c.expect("grad/target")).to(dev)
+    finals, losses = [], []
+    for graphed in (False, True):
+        model = build_model(recon, c, dev)
+        init = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        opt = recon.FusedAdam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+        gs = recon.GraphedTrainStep(model, opt, rays.shape[0], -1, warmup=1, white_bg=False) if graphed else None
+        torch.manual_seed(5)
+        losses.append([])
+        for it in range(14):
+            if graphed:
+                loss = gs.step(rays, target)
+            else:
+                rgb, _, _ = model(rays, None, white_bg=False, is_train=True)
+                loss = torch.mean((rgb - target) ** 2)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+            losses[-1].append(loss.item())
+        if graphed:
+            assert sorted(gs._graphs) == [False, True], list(gs._graphs)
+        finals.append({k: v.detach().clone() for k, v in model.state_dict().items()})
+    assert len(set(round(v, 4) for v in losses[0])) > 2          # the two backgrounds give visibly different losses
+    _same_trajectory(finals, init, losses)
