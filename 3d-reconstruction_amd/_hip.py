@@ -96,7 +96,7 @@ class TfPackJob(C.Structure):
 class TfRegJob(C.Structure):
     _fields_ = [("density", TfFactors), ("app", TfFactors), ("density_grad", TfFactorGrads), ("app_grad", TfFactorGrads),
                 ("grid", C.c_int * 3), ("w_ortho", C.c_float), ("w_l1", C.c_float), ("w_tv_density", C.c_float),
-                ("w_tv_app", C.c_float), ("loss", _fp), ("scale", _fp), ("want_grad", C.c_int)]
+                ("w_tv_app", C.c_float), ("loss", _fp), ("scale", _fp), ("want_grad", C.c_int), ("weights_dev", _fp)]
 
 
 ADAM_MAX_SEG, ADAM_CHUNK = 32, 8192

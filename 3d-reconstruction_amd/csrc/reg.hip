@@ -21,6 +21,7 @@ struct PlaneDesc {
     float ch, cw;     // weights of sum (d_h x)^2 and sum (d_w x)^2 (TV weight, the 1e-2 and the 2/count folded in)
     float l1;         // weight of sum |x|  (L1 weight / numel), 0 for the appearance planes
     int first_row;    // first row of this plane in the launch's flat row space
+    int tv_idx;       // which device weight scales ch / cw: 2 (density) or 3 (appearance)
 };
 struct PlaneJob {
     PlaneDesc p[6];
@@ -28,6 +29,7 @@ struct PlaneJob {
     float* loss;          // loss[0] += weighted total; loss[1] += sum of the TV terms; loss[2] += L1 term (planes part)
     const float* scale;   // device scalar multiplying the gradients, or NULL (= 1)
     int want_grad;
+    const float* wdev;    // NULL, or device weights [ortho, l1, tv_density, tv_app] multiplying the folded coefficients
 };
 
 // One workgroup per texel row (W * C floats, contiguous): no 64-bit index arithmetic, the row above / below are
@@ -40,6 +42,8 @@ __global__ __launch_bounds__(256) void reg_planes_kernel(const PlaneJob J) {
 #pragma unroll
         for (int q = 1; q < 6; ++q) k += (q < J.n && row >= J.p[q].first_row);
         const PlaneDesc& P = J.p[k];
+        const float wtv = J.wdev ? J.wdev[P.tv_idx] : 1.f, wl1 = J.wdev ? J.wdev[1] : 1.f;
+        const float Pch = P.ch * wtv, Pcw = P.cw * wtv, Pl1 = P.l1 * wl1;
         const int y = row - P.first_row, rowf = P.W * P.C;
         const float* xr = P.x + (size_t)y * rowf;
         float* gr = P.g + (size_t)y * rowf;
@@ -49,23 +53,23 @@ __global__ __launch_bounds__(256) void reg_planes_kernel(const PlaneJob J) {
             float4_t g = {0.f, 0.f, 0.f, 0.f};
             if (down) {
                 const float4_t d = v - ld4(xr + o + rowf);
-                g += d * (2.f * P.ch);
+                g += d * (2.f * Pch);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) tv = fmaf(P.ch * d[e], d[e], tv);      // each forward difference counted once
+                for (int e = 0; e < 4; ++e) tv = fmaf(Pch * d[e], d[e], tv);      // each forward difference counted once
             }
-            if (up) g += (v - ld4(xr + o - rowf)) * (2.f * P.ch);
+            if (up) g += (v - ld4(xr + o - rowf)) * (2.f * Pch);
             if (o + P.C < rowf) {
                 const float4_t d = v - ld4(xr + o + P.C);
-                g += d * (2.f * P.cw);
+                g += d * (2.f * Pcw);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) tv = fmaf(P.cw * d[e], d[e], tv);
+                for (int e = 0; e < 4; ++e) tv = fmaf(Pcw * d[e], d[e], tv);
             }
-            if (o >= P.C) g += (v - ld4(xr + o - P.C)) * (2.f * P.cw);
-            if (P.l1 != 0.f) {
+            if (o >= P.C) g += (v - ld4(xr + o - P.C)) * (2.f * Pcw);
+            if (Pl1 != 0.f) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    l1 = fmaf(P.l1, fabsf(v[e]), l1);
-                    g[e] += v[e] > 0.f ? P.l1 : (v[e] < 0.f ? -P.l1 : 0.f);       // torch.sign: 0 at 0
+                    l1 = fmaf(Pl1, fabsf(v[e]), l1);
+                    g[e] += v[e] > 0.f ? Pl1 : (v[e] < 0.f ? -Pl1 : 0.f);       // torch.sign: 0 at 0
                 }
             }
             if (J.want_grad) {
@@ -110,6 +114,7 @@ struct LineJob {
     float* loss;          // loss[0] += weighted total; loss[2] += L1 (lines part); loss[3] += ortho term
     const float* scale;
     int want_grad;
+    const float* wdev;
 };
 
 // One workgroup per (line tensor, component a).  Gram row a = V_a . V_b for all b (V = (C, G), C <= 64): threads
@@ -124,13 +129,14 @@ __global__ __launch_bounds__(256) void reg_lines_kernel(const LineJob J) {
 #pragma unroll
     for (int q = 1; q < 6; ++q) k += ((int)blockIdx.x >= J.l[q].first_wg);
     const LineDesc& L = J.l[k];
+    const float Lortho = L.ortho * (J.wdev ? J.wdev[0] : 1.f), Ll1 = L.l1 * (J.wdev ? J.wdev[1] : 1.f);
     const int a = (int)blockIdx.x - L.first_wg, tid = threadIdx.x, C = L.C, G = L.G;
     const float sc = J.scale ? *J.scale : 1.f;
     float dot[64];
 #pragma unroll
     for (int b = 0; b < 64; ++b) dot[b] = 0.f;
     float l1 = 0.f;
-    if (L.ortho != 0.f) {
+    if (Lortho != 0.f) {
         for (int z = tid; z < G; z += 256) {
             const float* row = L.v + (size_t)z * C;
             const float va = row[a];
@@ -155,9 +161,9 @@ __global__ __launch_bounds__(256) void reg_lines_kernel(const LineJob J) {
     float ortho = 0.f;
     if (tid < 64) {
         float d = 0.f;
-        if (L.ortho != 0.f && tid < C && tid != a) d = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+        if (Lortho != 0.f && tid < C && tid != a) d = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
         sgn[tid] = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-        ortho = fabsf(d) * L.ortho;
+        ortho = fabsf(d) * Lortho;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ortho += __shfl_xor(ortho, o, 64);
     }
@@ -166,14 +172,14 @@ __global__ __launch_bounds__(256) void reg_lines_kernel(const LineJob J) {
         const float* row = L.v + (size_t)z * C;
         const float x = row[a];
         float g = 0.f;
-        if (L.ortho != 0.f) {
+        if (Lortho != 0.f) {
             float acc = 0.f;
             for (int b = 0; b < C; ++b) acc = fmaf(sgn[b], row[b], acc);
-            g = 2.f * L.ortho * acc;
+            g = 2.f * Lortho * acc;
         }
-        if (L.l1 != 0.f) {
-            l1 = fmaf(L.l1, fabsf(x), l1);
-            g += x > 0.f ? L.l1 : (x < 0.f ? -L.l1 : 0.f);
+        if (Ll1 != 0.f) {
+            l1 = fmaf(Ll1, fabsf(x), l1);
+            g += x > 0.f ? Ll1 : (x < 0.f ? -Ll1 : 0.f);
         }
         if (J.want_grad) L.g[(size_t)z * C + a] += g * sc;
     }
@@ -203,6 +209,7 @@ extern "C" int tf_regularizers(const TfRegJob* job, tf_stream_t stream) {
     int line_wgs = 0;
     pj.loss = lj.loss = job->loss;
     pj.scale = lj.scale = job->scale;
+    pj.wdev = lj.wdev = job->weights_dev;
     pj.want_grad = lj.want_grad = job->want_grad;
     for (int part = 0; part < 2; ++part) {
         const TfFactors& F = part ? job->app : job->density;
@@ -220,6 +227,7 @@ extern "C" int tf_regularizers(const TfRegJob* job, tf_stream_t stream) {
             P.cw = tvw * 1e-2f * 2.f / ((float)C * H * (W - 1));
             P.l1 = part ? 0.f : job->w_l1 / ((float)C * H * W);
             P.first_row = pj.rows;
+            P.tv_idx = part ? 3 : 2;
             pj.rows += H;
             LineDesc& L = lj.l[part * 3 + i];
             L.v = F.line[i];

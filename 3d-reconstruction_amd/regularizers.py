@@ -25,7 +25,7 @@ class TVLoss(torch.nn.Module):
 
 # ---------------------------------------------------------------------------------------------------------
 # One-pass HIP version of the four terms for TensorVMSplit (tf_regularizers, csrc/reg.hip)
-def _reg_job(model, w_ortho, w_l1, w_tv_density, w_tv_app, loss, grads, scale):
+def _reg_job(model, w_ortho, w_l1, w_tv_density, w_tv_app, loss, grads, scale, weights_dev=None):
     import ctypes as C
     from . import _hip as H
     from .field import is_channel_last
@@ -50,6 +50,7 @@ def _reg_job(model, w_ortho, w_l1, w_tv_density, w_tv_app, loss, grads, scale):
     job.loss = loss.data_ptr()
     job.scale = scale.data_ptr() if scale is not None else None
     job.want_grad = int(grads is not None)
+    job.weights_dev = weights_dev.data_ptr() if weights_dev is not None else None
     return job
 
 
@@ -64,12 +65,12 @@ def _factor_params(model):
     return list(model.density_plane) + list(model.density_line) + list(model.app_plane) + list(model.app_line)
 
 
-def _launch(model, weights, grads, scale):
+def _launch(model, weights, grads, scale, weights_dev=None):
     import ctypes as C
     from . import _hip as H
     from .field import _stream
     loss = torch.zeros(4, dtype=torch.float32, device=model.density_plane[0].device)
-    job = _reg_job(model, *weights, loss, grads, scale)
+    job = _reg_job(model, *weights, loss, grads, scale, weights_dev)
     H.check(H.lib().tf_regularizers(C.byref(job), _stream()), "tf_regularizers")
     return loss
 
@@ -104,12 +105,15 @@ def fused_regularizers(model, ortho_weight=0.0, l1_weight=0.0, tv_weight_density
 
 
 @torch.no_grad()
-def add_regularizer_grads_(model, ortho_weight=0.0, l1_weight=0.0, tv_weight_density=0.0, tv_weight_app=0.0):
+def add_regularizer_grads_(model, ortho_weight=0.0, l1_weight=0.0, tv_weight_density=0.0, tv_weight_app=0.0,
+                           weights_dev=None):
     """The same sum, with its gradient ADDED to the existing `.grad` of the factor tensors in the same pass (call it
-    between `loss.backward()` and `optimizer.step()`); returns the 4 device floats [total, TV, L1, ortho]."""
+    between `loss.backward()` and `optimizer.step()`); returns the 4 device floats [total, TV, L1, ortho].
+    `weights_dev`: 4 device floats [ortho, l1, tv_density, tv_app] multiplying the host weights (pass 1.0 for those) —
+    for captured steps, where the per-iteration decay of the TV weights (train.py:336-339) must stay adjustable."""
     grads = {}
     for p in _factor_params(model):
         if p.grad is None:
             p.grad = torch.zeros_like(p)      # zeros_like keeps the channel-last strides
         grads[id(p)] = p.grad
-    return _launch(model, (ortho_weight, l1_weight, tv_weight_density, tv_weight_app), grads, None)
+    return _launch(model, (ortho_weight, l1_weight, tv_weight_density, tv_weight_app), grads, None, weights_dev)

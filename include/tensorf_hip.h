@@ -336,6 +336,9 @@ typedef struct TfRegJob {
     float* loss;
     const float* scale;
     int want_grad;
+    const float* weights_dev;  /* NULL, or 4 DEVICE floats [ortho, l1, tv_density, tv_app] that multiply the host weights
+                                * above (set those to 1): train.py:336-339 decays the TV weights every iteration, which a
+                                * hipGraph capture would otherwise freeze */
 } TfRegJob;
 int tf_regularizers(const TfRegJob* job, tf_stream_t stream);
 

@@ -170,6 +170,17 @@ def test_fused_regularisers_match_the_eager_terms(recon, grid, den, app):
         p = dict(model.named_parameters())[n]
         assert p.grad.stride() == p.stride()
         assert (p.grad - 0.5 - ref_g[n]).abs().max().item() <= 1e-5 * scale + 1e-7, n
+    # (3) the weights as DEVICE values (host weights 1): what a captured step uses while train.py:336-339 decays them
+    for n, p in model.named_parameters():
+        if n in names:
+            p.grad = torch.full_like(p, 0.5)
+    wd = torch.tensor([w["ortho_weight"], w["l1_weight"], w["tv_weight_density"], w["tv_weight_app"]], device=dev)
+    out3 = recon.add_regularizer_grads_(model, 1.0, 1.0, 1.0, 1.0, weights_dev=wd)
+    assert abs(out3[0].item() - ref.item()) <= 2e-6 * abs(ref.item())
+    for n in names:
+        scale = ref_g[n].abs().max().item()
+        p = dict(model.named_parameters())[n]
+        assert (p.grad - 0.5 - ref_g[n]).abs().max().item() <= 1e-5 * scale + 1e-7, n
 
 
 @pytest.mark.gpu
