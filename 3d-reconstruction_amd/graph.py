@@ -38,7 +38,7 @@ class GraphedTrainStep:
     EARLY_SORT_LIMITS = (500_000, 170_000)
 
     def __init__(self, model, optimizer, batch, n_samples, mask=None, ndc_ray=False, warmup=3, split=None,
-                 early_sort='auto', white_bg=True):
+                 early_sort='auto', white_bg=True, regularizers=False):
         self.model, self.opt = model, optimizer
         # split: capture backward and optimizer separately with the gradient all-reduce in between
         self.split = (dist.is_available() and dist.is_initialized() and
@@ -64,6 +64,11 @@ class GraphedTrainStep:
             raise NotImplementedError("GraphedTrainStep: random backgrounds (white_bg=False) are not combined with the "
                                       "data-parallel split step yet; use the eager loop")
         self._graphs = {}            # use_bg -> (graph, graph_opt)
+        # regularizers=True: tf_regularizers (train.py:340-371 in one pass) runs between the backward and the optimizer
+        # with its four weights read from device memory — set_regularizer_weights() before each step follows the
+        # schedule (the TV weights decay every iteration, train.py:336-339) without a new capture
+        self._regw = torch.zeros(4, device=next(model.parameters()).device) if regularizers else None
+        self._regw_host = None
         self._bg = True
         self.graph = None
         self._warm = max(1, warmup)   # >= 1: the first eager step also caches host copies of the geometry
@@ -76,7 +81,7 @@ class GraphedTrainStep:
         storage (both are replaced, not updated in place, by the schedule steps of train.py:300-311, 403-425)."""
         m = self.model
         lists = [getattr(m, n) for n in ("density_plane", "density_line", "app_plane", "app_line") if hasattr(m, n)]
-        return (id(m.alphaMask), id(self.opt), tuple(id(p) for lst in lists for p in lst))     # cheap: runs every step
+        return (id(m.alphaMask), id(self.opt), self.n_samples, tuple(id(p) for lst in lists for p in lst))     # cheap: runs every step
 
     def _fwd_bwd(self):
         model = self.model
@@ -93,11 +98,24 @@ class GraphedTrainStep:
         self.opt.zero_grad(set_to_none=True)
         rgb.backward(self._grad_rgb)
 
+    def set_regularizer_weights(self, ortho=0.0, l1=0.0, tv_density=0.0, tv_app=0.0):
+        """Weights of the four regulariser terms for the next step(s) (needs regularizers=True)."""
+        vals = [float(ortho), float(l1), float(tv_density), float(tv_app)]
+        if vals != self._regw_host:
+            self._regw.copy_(torch.tensor(vals).pin_memory(), non_blocking=True)
+            self._regw_host = vals
+
+    def _regs_and_opt(self):
+        if self._regw is not None:      # rank-invariant terms: added after the data gradients have been reduced
+            from .regularizers import add_regularizer_grads_
+            add_regularizer_grads_(self.model, 1.0, 1.0, 1.0, 1.0, weights_dev=self._regw)
+        self.opt.step()
+
     def _body(self):
         self._fwd_bwd()
         if self.split:
             parallel.allreduce_gradients(self.model, average=False)
-        self.opt.step()
+        self._regs_and_opt()
 
     def _stage(self, rays, target, ids=None):
         if ids is None:
@@ -180,7 +198,7 @@ class GraphedTrainStep:
             self._fwd_bwd()
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2, stream=self._side, pool=g.pool(), capture_error_mode="thread_local"):
-            self.opt.step()
+            self._regs_and_opt()
         self._graphs[self._bg] = (g, g2)
         self.graph, self.graph_opt = g, g2
         g.replay()

@@ -51,9 +51,13 @@ def psnr(mse):
     return -10.0 * math.log(max(float(mse), 1e-12)) / math.log(10.0)     # loss.py:46-47
 
 
-def train(tensorf, allrays, allrgbs, cfg=None, device="cuda", rank=0, world=1, log_every=0, seed=20211202):
+def train(tensorf, allrays, allrgbs, cfg=None, device="cuda", rank=0, world=1, log_every=0, seed=20211202, graphed=False):
     """Runs the schedule on `tensorf`; `allrays` (N,6) / `allrgbs` (N,3) may live on the CPU (as in the reference)
-    or on the GPU.  Returns a history dict (loss / PSNR per step, events)."""
+    or on the GPU.  Returns a history dict (loss / PSNR per step, events).
+
+    graphed=True drives every iteration through `GraphedTrainStep` (forward, MSE, backward, regularisers, Adam replayed
+    from a hipGraph; re-captured after each schedule event): same schedule, same host RNG stream, the rays are kept on
+    the GPU.  Not with `free_reg` (the FreeNeRF masks change every iteration)."""
     c = dict(DEFAULTS)
     c.update(cfg or {})
     aabb = tensorf.aabb
@@ -79,47 +83,60 @@ def train(tensorf, allrays, allrgbs, cfg=None, device="cuda", rank=0, world=1, l
     hist = dict(loss=[], psnr=[], events=[], n_samples=[])
     # park the objects that exist now in the collector's permanent generation: at ~1 ms per step a full cyclic
     # collection over the set-up's long-lived objects (a few ms) would otherwise recur every handful of steps
+    gs = None
+    if graphed:
+        from .graph import GraphedTrainStep
+        if c["free_reg"] or not fused_supported(tensorf) or c.get("optimizer", "fused") == "torch":
+            raise ValueError("harness.train(graphed=True) needs the fused regularisers / FusedAdam and no free_reg masks")
+        allrays, allrgbs = allrays.to(device).float().contiguous(), allrgbs.to(device).float().contiguous()
+        gs = GraphedTrainStep(tensorf, opt, batch, nSamples, ndc_ray=c["ndc_ray"], white_bg=c["white_bg"], warmup=1,
+                              regularizers=True)
     gc.collect()
     gc.freeze()
     for it in range(n_iters):
         ids = parallel.shard_ids(sampler.nextids(), rank, world).to(allrays.device)
-        rays_train, rgb_train = allrays[ids], allrgbs[ids].to(device)
-        mask = None
-        if c["free_reg"]:
-            mask = get_free_mask(pos_bl=tensorf.pos_bit_length, view_bl=tensorf.view_bit_length,
-                                 fea_bl=tensorf.fea_bit_length, den_bl=tensorf.density_n_comp,
-                                 app_bl=tensorf.app_n_comp, step=it, total_step=n_iters, device=device)   # train.py:303-318
-        rgb_map, _, depth_map, _, _, n = OctreeRender_trilinear_fast(
-            rays_train, tensorf, mask, chunk=batch, N_samples=nSamples, white_bg=c["white_bg"], ndc_ray=c["ndc_ray"],
-            device=device, is_train=True)
-        loss = torch.mean((rgb_map - rgb_train) ** 2)
         if tv_d > 0:
             tv_d *= lr_factor
         if tv_a > 0:
             tv_a *= lr_factor
         use_ortho = ortho_w if hasattr(tensorf, "vector_comp_diffs") else 0.0
-        if c.get("fused_regularizers", True) and fused_supported(tensorf):
-            # train.py:340-371 in one pass over the factor tensors (tf_regularizers): the terms do not depend on the
-            # rays, so their gradient is added after the data gradients have been reduced across ranks
-            opt.zero_grad()
-            loss.backward()
-            parallel.allreduce_gradients(tensorf)
-            if max(use_ortho, l1_w, tv_d, tv_a) > 0:
-                add_regularizer_grads_(tensorf, use_ortho, l1_w, max(tv_d, 0.0), max(tv_a, 0.0))
+        if gs is not None:       # the iteration below, replayed from a hipGraph (re-captured after schedule events)
+            gs.opt, gs.n_samples = opt, nSamples
+            gs.set_regularizer_weights(use_ortho, l1_w, max(tv_d, 0.0), max(tv_a, 0.0))
+            loss = gs.step(allrays, allrgbs, ids)
         else:
-            total = loss
-            if use_ortho > 0:
-                total = total + use_ortho * tensorf.vector_comp_diffs()
-            if l1_w > 0:
-                total = total + l1_w * tensorf.density_L1()
-            if tv_d > 0:
-                total = total + tensorf.TV_loss_density(tvreg) * tv_d
-            if tv_a > 0:
-                total = total + tensorf.TV_loss_app(tvreg) * tv_a
-            opt.zero_grad()
-            total.backward()
-            parallel.allreduce_gradients(tensorf)
-        opt.step()
+            rays_train, rgb_train = allrays[ids], allrgbs[ids].to(device)
+            mask = None
+            if c["free_reg"]:
+                mask = get_free_mask(pos_bl=tensorf.pos_bit_length, view_bl=tensorf.view_bit_length,
+                                     fea_bl=tensorf.fea_bit_length, den_bl=tensorf.density_n_comp,
+                                     app_bl=tensorf.app_n_comp, step=it, total_step=n_iters, device=device)   # train.py:303-318
+            rgb_map, _, depth_map, _, _, n = OctreeRender_trilinear_fast(
+                rays_train, tensorf, mask, chunk=batch, N_samples=nSamples, white_bg=c["white_bg"], ndc_ray=c["ndc_ray"],
+                device=device, is_train=True)
+            loss = torch.mean((rgb_map - rgb_train) ** 2)
+            if c.get("fused_regularizers", True) and fused_supported(tensorf):
+                # train.py:340-371 in one pass over the factor tensors (tf_regularizers): the terms do not depend on the
+                # rays, so their gradient is added after the data gradients have been reduced across ranks
+                opt.zero_grad()
+                loss.backward()
+                parallel.allreduce_gradients(tensorf)
+                if max(use_ortho, l1_w, tv_d, tv_a) > 0:
+                    add_regularizer_grads_(tensorf, use_ortho, l1_w, max(tv_d, 0.0), max(tv_a, 0.0))
+            else:
+                total = loss
+                if use_ortho > 0:
+                    total = total + use_ortho * tensorf.vector_comp_diffs()
+                if l1_w > 0:
+                    total = total + l1_w * tensorf.density_L1()
+                if tv_d > 0:
+                    total = total + tensorf.TV_loss_density(tvreg) * tv_d
+                if tv_a > 0:
+                    total = total + tensorf.TV_loss_app(tvreg) * tv_a
+                opt.zero_grad()
+                total.backward()
+                parallel.allreduce_gradients(tensorf)
+            opt.step()
         for g in opt.param_groups:
             g["lr"] = g["lr"] * lr_factor
         if log_every and (it % log_every == 0 or it == n_iters - 1):

@@ -44,8 +44,10 @@ def _reg_job(model, w_ortho, w_l1, w_tv_density, w_tv_app, loss, grads, scale, w
                     raise H.HipError("fused regularisers: a gradient is not laid out like its parameter")
                 fg.plane[i], fg.line[i] = gp.data_ptr(), gl.data_ptr()
         fg.n_rep, fg.rep_stride = 1, 0
+    geom = getattr(model, "_geom", None)        # host copy of the geometry (no device read: usable inside a capture)
+    grid = [int(g) for g in geom["grid"]] if geom is not None else [int(g) for g in model.gridSize.tolist()]
     for k in range(3):
-        job.grid[k] = int(model.gridSize[k])
+        job.grid[k] = grid[k]
     job.w_ortho, job.w_l1, job.w_tv_density, job.w_tv_app = float(w_ortho), float(w_l1), float(w_tv_density), float(w_tv_app)
     job.loss = loss.data_ptr()
     job.scale = scale.data_ptr() if scale is not None else None

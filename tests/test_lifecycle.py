@@ -217,3 +217,36 @@ def test_graphed_step_recaptures_after_schedule_steps(recon):
     assert gs.graph is not None and gs.graph is not g1
     assert all(np.isfinite(v) for v in (l0, l1, l2, l3))
     assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+@pytest.mark.gpu
+def test_graphed_harness_follows_the_eager_schedule(recon):
+    """harness.train(graphed=True): every iteration replayed from a hipGraph (regularisers with device-resident weights,
+    re-capture after alpha-mask update / shrink / up-sampling) ends where the eager loop ends."""
+    from recon_amd import synthetic as S, harness
+    dev = "cuda:0"
+    aabb = torch.tensor(S.LEGO_AABB, device=dev)
+    args = S.lego_args(density_n_comp=(8, 8, 8), app_n_comp=(16, 16, 16))
+    args["featureC"] = 64
+    torch.manual_seed(0)
+    teacher = recon.TensorVMSplit(args, aabb, [32] * 3, S.LEGO_NEAR_FAR, dev)
+    S.make_trained_like(teacher, recon.AlphaGridMask, mask_res=32)
+    rays = S.blender_rays(3, H=48, W=48, seed=3).to(dev)
+    with torch.no_grad():
+        gt = recon.OctreeRender_trilinear_fast(rays, teacher, chunk=4096, white_bg=True, device=dev)[0]
+    cfg = dict(n_iters=200, batch_size=2048, N_voxel_init=16 ** 3, N_voxel_final=32 ** 3, upsamp_list=[140, 170],
+               update_AlphaMask_list=[120], TV_weight_density=0.01, TV_weight_app=0.01, L1_weight_inital=8e-5,
+               L1_weight_rest=4e-5, Ortho_weight=0.01)
+    out = {}
+    for graphed in (False, True):
+        torch.manual_seed(11)
+        student = recon.TensorVMSplit(args, aabb, [16] * 3, S.LEGO_NEAR_FAR, dev)
+        torch.manual_seed(12)
+        hist = harness.train(student, rays, gt, cfg, device=dev, log_every=20, seed=1, graphed=graphed)
+        out[graphed] = (hist, harness.evaluate_psnr(student, rays[:2304], gt[:2304], device=dev), student.gridSize.tolist())
+    he, pe, ge = out[False]
+    hg, pg, gg = out[True]
+    assert [e[:2] for e in hg["events"]] == [e[:2] for e in he["events"]] and ge == gg
+    assert hg["n_samples"] == he["n_samples"]
+    assert abs(hg["psnr"][0][1] - he["psnr"][0][1]) < 0.05, (hg["psnr"][0], he["psnr"][0])      # same first step
+    assert pg > 15.0 and abs(pg - pe) < 1.5, (pg, pe)
