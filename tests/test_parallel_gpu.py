@@ -69,7 +69,8 @@ def _worker(rank, world, port, q):
         # 2. the split hipGraph step: same parameters on every rank after several steps, loss goes down
         model.zero_grad(set_to_none=True)
         opt = recon.FusedAdam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
-        gs = recon.GraphedTrainStep(model, opt, ids.numel(), N, warmup=1)
+        gs = recon.GraphedTrainStep(model, opt, ids.numel(), N, warmup=1, regularizers=True)
+        gs.set_regularizer_weights(0.01, 8e-5, 0.01, 0.01)      # rank-invariant terms, added after the exchange
         out["split"] = gs.split
         losses = []
         for it in range(8):
