@@ -181,9 +181,13 @@ def render_with_grad(model, rays, mask, white_bg, is_train, ndc_ray, N_samples):
     if model.shadingMode in ('SH', 'RGB'):
         raise H.HipError("training with the SH / RGB heads is not implemented in the HIP backward "
                          "(the reference cannot construct them either, models/tensorBase.py:89-98)")
+    # the (name, parameter) list is cached; only the factor tensors are ever replaced (shrink / upsample_volume_grid /
+    # load), so their identities are the cache key — walking model.parameters() every call costs 0.1 ms of host time
+    sig = tuple(id(p) for n in ("density_plane", "density_line", "app_plane", "app_line") if hasattr(model, n)
+                for p in getattr(model, n)) + (id(model.basis_mat.weight),) + \
+        tuple(id(p) for p in model.renderModule.parameters())
     cache = model._named_cache
-    if cache is None or any(a is not b for a, b in zip(cache[1], model.parameters())) or \
-            len(cache[1]) != sum(1 for _ in model.parameters()):
+    if cache is None or cache[2] != sig:
         named = list(model.named_parameters())
-        cache = model._named_cache = (tuple(n for n, _ in named), [p for _, p in named])
+        cache = model._named_cache = (tuple(n for n, _ in named), [p for _, p in named], sig)
     return _RenderFn.apply(model, rays, mask, white_bg, is_train, ndc_ray, N_samples, cache[0], *cache[1])
