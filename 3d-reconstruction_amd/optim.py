@@ -32,6 +32,7 @@ class FusedAdam(torch.optim.Optimizer):
         if len({(g['betas'], g['eps']) for g in self.param_groups}) != 1:
             raise ValueError("FusedAdam: betas / eps must be the same for every parameter group")
         self._flat = None        # (m_flat, v_flat, offsets)
+        self._jobs = None        # cached TfAdamJob structs (only the gradient pointers change from step to step)
         self._lr_host = None
         self._lr_dev = self._lr_pin = self._step_dev = None
 
@@ -69,6 +70,7 @@ class FusedAdam(torch.optim.Optimizer):
                     self._step_dev.fill_(float(loaded[2]))
             st['step'] = self._step_dev
         self._flat = (m, v, offs, [id(p) for _, p in ps])
+        self._jobs = None
         self._lr_dev = torch.zeros(len(self.param_groups), device=dev)
         self._lr_pin = torch.zeros(len(self.param_groups), pin_memory=True)
         self._lr_host = None
@@ -106,31 +108,38 @@ class FusedAdam(torch.optim.Optimizer):
         self.sync_lr()
         m, v, offs, _ = self._flat
         one_launch = len(ps) <= H.ADAM_MAX_SEG       # then the kernel advances the step count itself
-        g0 = self.param_groups[0]
         lib, st = H.lib(), _stream()
-        chunk0 = 0
-        for s0 in range(0, len(ps), H.ADAM_MAX_SEG):
-            job = H.TfAdamJob()
-            part = ps[s0:s0 + H.ADAM_MAX_SEG]
-            run = 0
+        if self._jobs is None:                       # everything but the gradient pointers is fixed for this optimizer
+            g0 = self.param_groups[0]
+            self._jobs, chunk0 = [], 0
+            for s0 in range(0, len(ps), H.ADAM_MAX_SEG):
+                job = H.TfAdamJob()
+                part = ps[s0:s0 + H.ADAM_MAX_SEG]
+                run = 0
+                for i, (gi, p) in enumerate(part):
+                    sg = job.seg[i]
+                    sg.p = p.data_ptr()
+                    sg.m, sg.v = m.data_ptr() + 4 * offs[s0 + i], v.data_ptr() + 4 * offs[s0 + i]
+                    sg.n, sg.group = p.numel(), gi
+                    run += (p.numel() + H.ADAM_CHUNK - 1) // H.ADAM_CHUNK
+                    job.chunk_end[i] = run
+                job.n_seg = len(part)
+                job.lrs, job.step = self._lr_dev.data_ptr(), self._step_dev.data_ptr()
+                job.beta1, job.beta2, job.eps = g0['betas'][0], g0['betas'][1], g0['eps']
+                if one_launch:
+                    job.step_rw, job.arrivals = self._step_dev.data_ptr(), self._arrivals.data_ptr()
+                job.touched = self._touched.data_ptr() + 4 * chunk0
+                chunk0 += run
+                self._jobs.append((job, part, [p.data_ptr() for _, p in part]))
+        for job, part, ptrs in self._jobs:
             for i, (gi, p) in enumerate(part):
                 g = p.grad
                 if not _dense_like(p, g):
                     raise H.HipError("FusedAdam: a gradient is not laid out like its parameter (expected the HIP "
                                      "backward's gradient views)")
-                sg = job.seg[i]
-                sg.p, sg.g = p.data_ptr(), g.data_ptr()
-                sg.m, sg.v = m.data_ptr() + 4 * offs[s0 + i], v.data_ptr() + 4 * offs[s0 + i]
-                sg.n, sg.group = p.numel(), gi
-                run += (p.numel() + H.ADAM_CHUNK - 1) // H.ADAM_CHUNK
-                job.chunk_end[i] = run
-            job.n_seg = len(part)
-            job.lrs, job.step = self._lr_dev.data_ptr(), self._step_dev.data_ptr()
-            job.beta1, job.beta2, job.eps = g0['betas'][0], g0['betas'][1], g0['eps']
-            if one_launch:
-                job.step_rw, job.arrivals = self._step_dev.data_ptr(), self._arrivals.data_ptr()
-            job.touched = self._touched.data_ptr() + 4 * chunk0
-            chunk0 += run
+                if p.data_ptr() != ptrs[i]:
+                    raise H.HipError("FusedAdam: a parameter's storage was replaced; build a new optimizer")
+                job.seg[i].g = g.data_ptr()
             H.check(lib.tf_adam_step(C.byref(job), st), "tf_adam_step")
         if not one_launch:
             self._step_dev += 1
