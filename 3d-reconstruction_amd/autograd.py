@@ -7,6 +7,7 @@ basis matrix, appearance factors) and hands PyTorch one gradient tensor per para
 parameter (channel-last for the factor tensors), so `torch.optim.Adam` and the reference training loop
 (train.py:374-376) work unchanged."""
 import ctypes as C
+import weakref
 
 import torch
 
@@ -96,6 +97,7 @@ class _RenderFn(torch.autograd.Function):
         c = model._run_forward(rays, mask, white_bg, is_train, ndc_ray, N_samples, save_valid=True,
                                after_march=lambda ws, field, shade: _early_sort(model, ws, field, shade, named_fwd))
         ws = c['ws']
+        ws.owner = weakref.ref(ctx)          # lets the pool reclaim the workspace if this graph is dropped un-backwarded
         ctx.early_bufs = None
         if c.get('sorted_on') is not None:      # (second stream, gradient buffers): the buffers travel on ctx only —
             c['sorted_on'], ctx.early_bufs = c['sorted_on']   # a second owner (model.last) would make autograd copy them
@@ -172,7 +174,7 @@ class _RenderFn(torch.autograd.Function):
         if n_rep:
             model._timed("tf_reduce_replicas", lib.tf_reduce_replicas, rep0, n_rep, line_len, line_len, flat.data_ptr(), st)
         out = tuple(grads[n] if p.requires_grad else None for n, p in named)
-        ws.busy = False     # stream order: the next forward that takes this workspace runs after these kernels
+        ws.busy, ws.owner = False, None     # stream order: the next forward that takes this workspace runs after these kernels
         ctx.c = None
         return (None,) * 8 + out
 

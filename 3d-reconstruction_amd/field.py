@@ -195,6 +195,7 @@ class _Workspace:
         self.R, self.N, self.seg_cap, self.cap, self.words = R, N, seg_cap, cap, words
         self.save_valid, self.debug, self.binned_cfg = save_valid, debug, binned
         self.busy = False
+        self.owner = None      # weakref to the autograd ctx that holds this (training) workspace until its backward
         self.counters2d = self.counters.view(H.N_SHARDS, H.SHARD_STRIDE)
 
 
@@ -430,6 +431,10 @@ class TensorBase(nn.Module):
             H.check(H.lib().tf_pack_matrices(C.byref(job), _stream()), "tf_pack_matrices")
         return out
 
+    def invalidate_packed_weights(self):
+        """Forget which weights the padded copies were made from (their buffers are kept and refilled on next use)."""
+        self._pack_cache = {k: (None, v[1]) for k, v in self._pack_cache.items()}
+
     def _pe_blocks(self, enc_mask, dev):
         """Order of the encoding blocks per head (models/mlp.py:41-66, 84-103, 126-153)."""
         em = enc_mask or {'pos': None, 'view': None, 'fea': None}
@@ -544,8 +549,10 @@ class TensorBase(nn.Module):
             # workspace stays `busy` from its forward until the end of its backward
             pool = self._train_ws.setdefault(key, [])
             for w in pool:
-                if not w.busy:
-                    w.busy = True
+                # free, or taken by a forward whose autograd graph was dropped without a backward (validation without
+                # no_grad, a discarded loss, an exception): stream order makes the reuse safe either way
+                if not w.busy or (w.owner is not None and w.owner() is None):
+                    w.busy, w.owner = True, None
                     return w
         ws = self._ws_cache.get(key)
         if ws is None or save_valid:

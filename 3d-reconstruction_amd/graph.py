@@ -81,7 +81,14 @@ class GraphedTrainStep:
         storage (both are replaced, not updated in place, by the schedule steps of train.py:300-311, 403-425)."""
         m = self.model
         lists = [getattr(m, n) for n in ("density_plane", "density_line", "app_plane", "app_line") if hasattr(m, n)]
-        return (id(m.alphaMask), id(self.opt), self.n_samples, tuple(id(p) for lst in lists for p in lst))     # cheap: runs every step
+        # the objects themselves, not their id(): CPython hands the address of a freed mask / optimizer to the next
+        # allocation, and a stale graph replayed on a coincidence would read freed tables.  Compared with `is`.
+        return (m.alphaMask, self.opt, self.n_samples) + tuple(p for lst in lists for p in lst)     # cheap: runs every step
+
+    @staticmethod
+    def _same(a, b):
+        return a is not None and b is not None and len(a) == len(b) and all(
+            (x == y) if isinstance(x, int) else (x is y) for x, y in zip(a, b))
 
     def _fwd_bwd(self):
         model = self.model
@@ -148,7 +155,7 @@ class GraphedTrainStep:
     def _step(self):
         if hasattr(self.opt, "sync_lr") and self.opt._lr_dev is not None:
             self.opt.sync_lr()                                    # FusedAdam: lr schedule follows the host values
-        if self._graphs and self._signature() != self._captured_for:
+        if self._graphs and not self._same(self._signature(), self._captured_for):
             # the model changed under the graph (updateAlphaMask / shrink / upsample_volume_grid replace the mask and the
             # parameters, train.py:300-311): the captured pointers are stale -> warm up and capture again
             self._graphs = {}
@@ -160,6 +167,7 @@ class GraphedTrainStep:
             if self.split:
                 parallel.allreduce_gradients(self.model, average=False)      # on model.grad_flat: a static buffer of the graph's pool
                 hit[1].replay()
+            self._after_replay()
             return self.loss
         self.model.static_jitter = self.jitter
         cur = torch.cuda.current_stream()
@@ -191,6 +199,7 @@ class GraphedTrainStep:
             self._graphs[self._bg] = (g, None)
             self.graph = g
             g.replay()                                            # capture only records; run this step now
+            self._after_replay()
             return self.loss
         # thread-local capture mode: the process group's helper threads (RCCL proxy / watchdog, gloo workers) may
         # make HIP calls of their own while this thread captures; they never touch the captured stream
@@ -204,4 +213,12 @@ class GraphedTrainStep:
         g.replay()
         parallel.allreduce_gradients(self.model, average=False)
         g2.replay()
+        self._after_replay()
         return self.loss
+
+    def _after_replay(self):
+        """A replay runs Adam behind autograd's back: the parameters' `_version` counters (bumped once, at capture) no
+        longer say that the weights changed, and the replay itself refreshed the padded weight copies BEFORE its Adam
+        update — so they are one step behind the weights now.  Drop the cache tags: the next eager forward (validation
+        between replays, compute_appfeature, the warm-up step after a schedule event) packs again."""
+        self.model.invalidate_packed_weights()

@@ -44,7 +44,11 @@ DEFAULTS = dict(n_iters=3000, batch_size=4096, lr_init=0.02, lr_basis=1e-3, lr_d
                 lr_decay_target_ratio=0.1, lr_upsample_reset=1, N_voxel_init=128 ** 3, N_voxel_final=300 ** 3,
                 upsamp_list=[2000, 3000, 4000, 5500, 7000], update_AlphaMask_list=[2000, 4000], step_ratio=0.5,
                 alpha_mask_reso=None, Ortho_weight=0.0, L1_weight_inital=0.0, L1_weight_rest=0.0,
-                TV_weight_density=0.0, TV_weight_app=0.0, free_reg=False, white_bg=True, ndc_ray=False)
+                TV_weight_density=0.0, TV_weight_app=0.0, free_reg=False, white_bg=True, ndc_ray=False,
+                # samples per ray after an up-sampling: "reference" = train.py:472 `min(nSamples, cal_n_samples(...))`
+                # (this fork: N never grows past the initial grid's count, 443 for 128^3); "upstream" = TensoRF's
+                # `min(args.nSamples = 1e6, cal_n_samples(...))` (N follows the grid: 1039 at 300^3)
+                n_samples_rule="reference")
 
 
 def psnr(mse):
@@ -93,6 +97,7 @@ def train(tensorf, allrays, allrgbs, cfg=None, device="cuda", rank=0, world=1, l
                               regularizers=True)
     gc.collect()
     gc.freeze()
+    mask = None
     for it in range(n_iters):
         ids = parallel.shard_ids(sampler.nextids(), rank, world).to(allrays.device)
         if tv_d > 0:
@@ -106,7 +111,6 @@ def train(tensorf, allrays, allrgbs, cfg=None, device="cuda", rank=0, world=1, l
             loss = gs.step(allrays, allrgbs, ids)
         else:
             rays_train, rgb_train = allrays[ids], allrgbs[ids].to(device)
-            mask = None
             if c["free_reg"]:
                 mask = get_free_mask(pos_bl=tensorf.pos_bit_length, view_bl=tensorf.view_bit_length,
                                      fea_bl=tensorf.fea_bit_length, den_bl=tensorf.density_n_comp,
@@ -146,7 +150,8 @@ def train(tensorf, allrays, allrgbs, cfg=None, device="cuda", rank=0, world=1, l
         if it in mask_list:                                                                # train.py:450-465
             g3 = tensorf.gridSize.tolist()
             reso_mask = c["alpha_mask_reso"] or (g3 if g3[0] * g3[1] * g3[2] < 256 ** 3 else [256, 256, 256])
-            new_aabb = tensorf.updateAlphaMask(tuple(reso_mask))
+            # train.py:456 hands the FreeNeRF density mask of this iteration to the alpha-volume rebuild
+            new_aabb = tensorf.updateAlphaMask(tuple(reso_mask), mask['decomp']['den'] if mask is not None else None)
             if it == mask_list[0]:
                 tensorf.shrink(new_aabb)
                 l1_w = c["L1_weight_rest"]
@@ -154,11 +159,13 @@ def train(tensorf, allrays, allrgbs, cfg=None, device="cuda", rank=0, world=1, l
             if not c["ndc_ray"] and it == mask_list[-1] and len(mask_list) > 1:
                 allrays, allrgbs = tensorf.filtering_rays(allrays, allrgbs)
                 sampler = SimpleSampler(allrays.shape[0], batch * world, seed + it)
-            opt = make_opt(c["lr_init"] * lr_factor ** it, c["lr_basis"] * lr_factor ** it)
+            # shrink replaced the parameters: the optimizer is rebuilt at the CURRENT learning rates (decayed it + 1 times)
+            opt = make_opt(c["lr_init"] * lr_factor ** (it + 1), c["lr_basis"] * lr_factor ** (it + 1))
         if it in upsamp_list:                                                              # train.py:468-481
             n_voxels = n_voxel_list.pop(0)
             reso_cur = N_to_reso(n_voxels, tensorf.aabb)
-            nSamples = min(int(1e6), cal_n_samples(reso_cur, c["step_ratio"]))
+            nSamples = min(nSamples if c["n_samples_rule"] == "reference" else int(1e6),
+                           cal_n_samples(reso_cur, c["step_ratio"]))                      # train.py:472
             tensorf.upsample_volume_grid(reso_cur)
             scale = 1.0 if c["lr_upsample_reset"] else c["lr_decay_target_ratio"] ** (it / n_iters)
             opt = make_opt(c["lr_init"] * scale, c["lr_basis"] * scale)

@@ -34,7 +34,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._flat = None        # (m_flat, v_flat, offsets)
         self._jobs = None        # cached TfAdamJob structs (only the gradient pointers change from step to step)
         self._lr_host = None
-        self._lr_dev = self._lr_pin = self._step_dev = None
+        self._lr_dev = self._step_dev = None
 
     def _params(self):
         return [(gi, p) for gi, g in enumerate(self.param_groups) for p in g['params']]
@@ -72,7 +72,6 @@ class FusedAdam(torch.optim.Optimizer):
         self._flat = (m, v, offs, [id(p) for _, p in ps])
         self._jobs = None
         self._lr_dev = torch.zeros(len(self.param_groups), device=dev)
-        self._lr_pin = torch.zeros(len(self.param_groups), pin_memory=True)
         self._lr_host = None
 
     def load_state_dict(self, state_dict):
@@ -87,8 +86,10 @@ class FusedAdam(torch.optim.Optimizer):
         if lrs != self._lr_host:
             if torch.cuda.is_current_stream_capturing():
                 raise H.HipError("FusedAdam: learning rates changed inside a graph capture")
-            self._lr_pin.copy_(torch.tensor(lrs))
-            self._lr_dev.copy_(self._lr_pin, non_blocking=True)
+            # a FRESH pinned tensor per upload (the caching host allocator keeps it alive until the copy has run): with
+            # graph replays the host runs many steps ahead of the GPU, and rewriting one staging buffer would let the
+            # copy of step k read the rates of a later step
+            self._lr_dev.copy_(torch.tensor(lrs, dtype=torch.float32).pin_memory(), non_blocking=True)
             self._lr_host = lrs
 
     @torch.no_grad()

@@ -250,3 +250,68 @@ def test_graphed_harness_follows_the_eager_schedule(recon):
     assert hg["n_samples"] == he["n_samples"]
     assert abs(hg["psnr"][0][1] - he["psnr"][0][1]) < 0.05, (hg["psnr"][0], he["psnr"][0])      # same first step
     assert pg > 15.0 and abs(pg - pe) < 1.5, (pg, pe)
+
+
+@pytest.mark.gpu
+def test_eval_between_graph_replays_sees_the_current_weights(recon):
+    """A replay updates W1 / W2 / basis without bumping their `_version`, and refreshes the padded copies BEFORE its Adam
+    update: an eval after k replays must not run on copies that are one optimizer step old (round-1 advisor finding).
+    eval, 3 replays, eval, 2 replays, eval — every eval against the oracle evaluated on the model's CURRENT state."""
+    from recon_amd import synthetic as S
+    from oracle import ref_torch as R
+    from tests.helpers import oracle_of
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    aabb = torch.tensor(S.LEGO_AABB, device=dev)
+    args = S.lego_args(density_n_comp=(8, 8, 8), app_n_comp=(16, 16, 16))
+    model = recon.TensorVMSplit(args, aabb, [40, 40, 40], S.LEGO_NEAR_FAR, dev)
+    S.make_trained_like(model, recon.AlphaGridMask, mask_res=32, radius=0.7)
+    allrays = S.blender_rays(1)
+    rays = allrays[torch.randperm(allrays.shape[0], generator=torch.Generator().manual_seed(3))[:2048]].to(dev).contiguous()
+    target = torch.rand(2048, 3, generator=torch.Generator().manual_seed(4)).to(dev)
+    N = 150
+    # a large network learning rate makes a one-step-old W1 / W2 / basis visible in the image
+    opt = recon.FusedAdam(model.get_optparam_groups(0.02, 2e-2), betas=(0.9, 0.99))
+    gs = recon.GraphedTrainStep(model, opt, 2048, N, warmup=1)
+
+    def check():
+        with torch.no_grad():
+            rgb, _, _ = model(rays[:512], None, white_bg=True, is_train=False, N_samples=N)
+        cfg, params = oracle_of(model, "cpu")
+        ref, _, _ = R.render_rays(cfg, params, rays[:512].cpu(), None, white_bg=True, is_train=False, n_samples=N)
+        err = (rgb.cpu() - ref).abs().max().item()
+        assert err < 2e-4, err
+
+    check()
+    for _ in range(4):          # warm-up, capture, replays
+        gs.step(rays, target)
+    assert gs.graph is not None
+    check()
+    for _ in range(2):
+        gs.step(rays, target)
+    check()
+    feat = model.compute_appfeature(torch.rand(64, 3, device=dev) * 2 - 1)      # same packed basis copy
+    cfg, params = oracle_of(model, "cpu")
+    assert torch.isfinite(feat).all()
+
+
+@pytest.mark.gpu
+def test_training_workspace_is_reclaimed_when_no_backward_runs(recon):
+    """A grad-enabled forward whose result is dropped without a backward must not pin its pooled workspace forever
+    (round-1 advisor finding): the pool stays at one entry over many such forwards."""
+    from recon_amd import synthetic as S
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    aabb = torch.tensor(S.LEGO_AABB, device=dev)
+    model = recon.TensorVMSplit(S.lego_args(density_n_comp=(8, 8, 8), app_n_comp=(16, 16, 16)), aabb, [32] * 3,
+                                S.LEGO_NEAR_FAR, dev)
+    S.make_trained_like(model, recon.AlphaGridMask, mask_res=32, radius=0.7)
+    rays = S.blender_rays(1)[:1024].to(dev).contiguous()
+    seen = set()
+    for _ in range(8):
+        rgb, _, _ = model(rays, None, white_bg=True, is_train=True, N_samples=100)
+        seen.add(model.last["ws"].buf.data_ptr())
+        del rgb
+    assert len(seen) <= 2, seen
+    pools = list(model._train_ws.values())
+    assert len(pools) == 1 and len(pools[0]) <= 2
