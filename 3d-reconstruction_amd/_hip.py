@@ -64,7 +64,12 @@ class TfShade(C.Structure):
 
 class TfShadeGrads(C.Structure):
     _fields_ = [("w1", _fp), ("b1", _fp), ("w2", _fp), ("b2", _fp), ("w3", _fp), ("b3", _fp),
-                ("basis", _fp), ("app", TfFactorGrads), ("dv_out", _fp), ("wslab", _fp), ("direct_scatter", C.c_int)]
+                ("basis", _fp), ("app", TfFactorGrads), ("dv_out", _fp), ("wslab", _fp), ("direct_scatter", C.c_int),
+                ("x_saved", _fp), ("rgb_fwd", _fp)]
+
+
+class TfShadeSave(C.Structure):
+    _fields_ = [("x", _fp), ("v", _fp)]
 
 
 class TfBinJob(C.Structure):
@@ -130,7 +135,7 @@ _SIGS = {
     "tf_mse_grad": [_fp, _fp, C.c_int, C.c_float, _fp, _fp, _fp],
     "tf_generate_rays": [C.POINTER(TfCamera), _fp, C.c_longlong, C.c_int, _fp, _fp],
     "tf_march_forward": [C.POINTER(TfField), C.POINTER(TfMarchIO), _fp],
-    "tf_shade_forward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, C.c_int, _fp],
+    "tf_shade_forward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, C.c_int, C.POINTER(TfShadeSave), _fp],
     "tf_composite_forward": [C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp, _fp, _fp],
     "tf_density_points": [C.POINTER(TfField), _fp, C.c_int, _fp, _fp],
     "tf_appfeature_points": [C.POINTER(TfShade), _fp, C.c_int, _fp, _fp],

@@ -24,7 +24,7 @@ namespace {
 // Wave w: feature tiles NFW*(w % FG) .. +NFW, sample tiles NSW*(w / FG) .. +NSW  (FG = 8 / SG feature groups).
 template <int FT, int NB>
 __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, const TileSrc src, float* __restrict__ rgb_out,
-                                                               float* __restrict__ feat_out) {
+                                                               float* __restrict__ feat_out, const TfShadeSave save) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // the only LDS object (16-B aligned base)
     constexpr int NT = 512, NW = 8, SG = FT < NW ? NW / FT : 1, FG = NW / SG, NFW = FT / FG, NSW = 4 / SG;
     const ShadeLds L = shade_lds(S);
@@ -108,6 +108,22 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
         }
         __syncthreads();
         TF_MARK(1);
+        if (save.v) {     // training: the product rows go back to HBM for the backward (dB = dfeat^T V), 16 B per lane
+            const int nat = S.n_app_total;
+            float* dst = save.v + (size_t)s0 * nat;
+            if ((nat & 3) == 0) {
+                const int w4 = nat >> 2;
+                const float inv = 1.f / (float)w4;
+                for (int q = tid; q < n * w4; q += NT) {
+                    int row, c4;
+                    row_quad(q, w4, inv, row, c4);
+                    *reinterpret_cast<f32x4*>(dst + (size_t)q * 4) = *reinterpret_cast<const f32x4*>(regA + row * L.sv + 4 * c4);
+                }
+            } else {
+                for (int smp = wave; smp < n; smp += NW)
+                    for (int c = lane; c < nat; c += 64) dst[(size_t)smp * nat + c] = regA[smp * L.sv + c];
+            }
+        }
 
         // ---- 2. basis: feat[s][f] = sum_k B[f][k] V[s][k]; (feature tile, sample tile) pairs dealt to the 8 waves
         for (int pr = wave; pr < 4 * NB; pr += NW) {
@@ -181,6 +197,16 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
         }
         __syncthreads();
         TF_MARK(3);
+        if (save.x) {     // training: the MLP input rows (zero padded to a multiple of 16) for the backward
+            const int w4 = kpad16(S.in_c) >> 2;
+            const float inv = 1.f / (float)w4;
+            float* dst = save.x + (size_t)s0 * (4 * w4);
+            for (int q = tid; q < n * w4; q += NT) {
+                int row, c4;
+                row_quad(q, w4, inv, row, c4);
+                *reinterpret_cast<f32x4*>(dst + (size_t)q * 4) = *reinterpret_cast<const f32x4*>(regB + row * L.sx + 4 * c4);
+            }
+        }
 
         // ---- 4. hidden layers
         const int FC = S.feature_c;
@@ -265,7 +291,7 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
     TF_FLUSH();
 }
 
-typedef void (*shade_fn_t)(const TfShade, const TileSrc, float*, float*);
+typedef void (*shade_fn_t)(const TfShade, const TileSrc, float*, float*, const TfShadeSave);
 
 template <int FT>
 shade_fn_t pick_nb(int nb) {
@@ -288,7 +314,8 @@ shade_fn_t pick_kernel(const TfShade& S) {
     return nullptr;
 }
 
-int launch_shade(const TfShade* S, const TileSrc& src, float* rgb_out, float* feat_out, int blocks, hipStream_t st) {
+int launch_shade(const TfShade* S, const TileSrc& src, float* rgb_out, float* feat_out, int blocks, hipStream_t st,
+                 TfShadeSave save = TfShadeSave{nullptr, nullptr}) {
     shade_fn_t fn = pick_kernel(*S);
     if (!fn) return (int)hipErrorInvalidValue;
     if (S->head == TF_HEAD_SH && S->app_dim != 27) return (int)hipErrorInvalidValue;
@@ -297,7 +324,7 @@ int launch_shade(const TfShade* S, const TileSrc& src, float* rgb_out, float* fe
     if (bytes > 160 * 1024 - 1024) return (int)hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(fn, dim3(blocks), dim3(512), bytes, st, *S, src, rgb_out, feat_out);
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(512), bytes, st, *S, src, rgb_out, feat_out, save);
     return TF_CHECK_LAUNCH();
 }
 
@@ -306,10 +333,12 @@ int launch_shade(const TfShade* S, const TileSrc& src, float* rgb_out, float* fe
 extern "C" {
 
 int tf_shade_forward(const TfShade* shade, const float* rays, int ndc, const int* counters, int seg_cap,
-                     const int* app_ray, const float* app_xyz, float* rgb_out, int max_workgroups, tf_stream_t stream) {
+                     const int* app_ray, const float* app_xyz, float* rgb_out, int max_workgroups,
+                     const TfShadeSave* save, tf_stream_t stream) {
     TileSrc src{counters, seg_cap, 0, app_ray, app_xyz, rays, ndc};
     const int wgs = max_workgroups > 0 && max_workgroups < 512 ? max_workgroups : 512;
-    return launch_shade(shade, src, rgb_out, nullptr, wgs, (hipStream_t)stream);
+    if (save && shade->head != TF_HEAD_MLP && save->x) return (int)hipErrorInvalidValue;   // X rows exist for MLP heads only
+    return launch_shade(shade, src, rgb_out, nullptr, wgs, (hipStream_t)stream, save ? *save : TfShadeSave{nullptr, nullptr});
 }
 
 int tf_appfeature_points(const TfShade* shade, const float* xyz_n, int n, float* out_feat, tf_stream_t stream) {

@@ -1,60 +1,30 @@
 // shade_bwd.hip — backward of the shading head + appearance lookup (autograd of tensoRF.py:230-263 /
 // :388-415 and mlp.py:27-155).   gfx950, wave64, fp32 MFMA.
 //
-// One persistent 512-thread workgroup (8 waves, 2 per SIMD) per CU walks 64-sample tiles of the packed app list.  Per tile it
-// recomputes the forward (gather -> V, basis -> feat, PE -> X, two hidden layers -> H1, H2, output) in
-// LDS, then back-propagates dL/dc:
-//     do  = dL/dc . c(1-c)                         dW3 += do^T H2          db3 += sum do
-//     dZ2 = (do W3) . [H2>0]     (in place of H2)  dW2 += dZ2^T H1         db2 += sum dZ2
-//     dZ1 = (W2^T dZ2) . [H1>0]  (in place of H1)  dW1 += dZ1^T X          db1 += sum dZ1
-//     dX  = W1^T dZ1             (in place of X)   dfeat = dX[:, :D] + PE'(feat) . dX[:, PE cols]
-//     dB += dfeat^T V                               dV = B^T dfeat (in place of V)
-//     dP / dL scatter-add with float atomics (4 lanes per sample, channel-last gradients).
-// The weight-gradient GEMMs (sample index = MFMA k dimension) accumulate in REGISTERS across the tiles of a
-// workgroup (104 VGPRs per lane at 2 waves per SIMD, no scratch: kernels that spill cannot be replayed from a
-// hipGraph on this stack) and are written once, in accumulator-fragment order, to the workgroup's slab in global
-// memory; wslab_reduce_kernel sums the slabs over the workgroups.
+// One persistent 512-thread workgroup (8 waves, 2 per SIMD) per CU walks <= 64-sample chunks of the packed app list.
+// The training forward (tf_shade_forward with TfShadeSave) has left, per packed sample, the MLP input row
+// X = [feat, view, PE blocks] and the product row V = plane*line; the sigmoid output is the forward's rgb.  So the
+// gather, the basis contraction, the positional encoding and the output layer are NOT recomputed: X and V are streamed
+// back (prefetched through registers one phase / one chunk ahead), only the two hidden layers are.  Per chunk:
+//     P1  X (registers -> LDS); do = dL/dc . c(1-c) from the forward's colours
+//     P2  H1 = relu(W1 X + b1)                                            MFMA, weights streamed from L2
+//     P3  H2 = relu(W2 H1 + b2); epilogue, per accumulator element: dW3 += do^T H2, dZ2 = (do W3) . [H2>0] (in place
+//         of H2), db2 += dZ2                                                MFMA
+//     P4  dZ1 = (W2^T dZ2) . [H1>0] -> its own buffer, db1 += dZ1;  dW2 += dZ2^T H1          MFMA (two GEMMs, no barrier)
+//     P5  dW1 += dZ1^T X;  dX = W1^T dZ1 -> its own buffer                                       MFMA (two GEMMs)
+//     P6  dfeat = dX[:, :D] + PE'(feat) . dX[:, PE cols];  V (registers -> LDS, over dZ1)
+//     P7  dB += dfeat^T V;  dV = B^T dfeat -> straight from the accumulators to dv_out             MFMA (two GEMMs)
+// 6 barriers per chunk (17 in round 1).  The weight-gradient GEMMs (k = sample index) read BOTH operands with one wide
+// LDS read per lane and 4 samples: lane (r, kq) reads E consecutive columns of row 4t + kq, element e of operand A
+// against element e' of operand B feeds accumulator tile (e, e') — rows E_a i + e, columns E_b j + e' of the product —
+// so one b128 + one b64 read feed 8 MFMAs (round 1: 36 scalar reads per 32).  The accumulators live in registers
+// across the chunks of a workgroup and are written once, in fragment order, to the workgroup's slab;
+// wslab_reduce_kernel folds the slabs and undoes the fragment order.
 #include "tf_shade.h"
 
 using namespace tf;
 
 namespace {
-
-enum { ROW = 0, COL = 1 };
-
-// operand fragment of 4 consecutive k for index `idx`: ROW: p[idx][k..k+3] (k contiguous);
-// COL: p[k..k+3][idx] (k strided).
-template <int MODE>
-__device__ __forceinline__ f32x4 ldfrag(const float* p, int ld, int idx, int k) {
-    if (MODE == ROW) return *reinterpret_cast<const f32x4*>(p + (size_t)idx * ld + k);
-    f32x4 r;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = p[(size_t)(k + e) * ld + idx];
-    return r;
-}
-
-// acc[i][j] += sum_k A(a_base+16i + r, k) * B(b_base+16j + r, k), k in [0, 16*kgroups)
-template <int NA, int NBT, int AM, int BM>
-__device__ __forceinline__ void mma_gen(const float* A, int lda, int a_base, const float* B, int ldb, int b_base,
-                                        int kgroups, f32x4 (&acc)[NA][NBT], int lane) {
-    const int r = lane & 15, kq = lane >> 4;
-#pragma unroll 1
-    for (int kg = 0; kg < kgroups; ++kg) {
-        const int k = 16 * kg + 4 * kq;
-        f32x4 a[NA], b[NBT];
-#pragma unroll
-        for (int i = 0; i < NA; ++i) a[i] = ldfrag<AM>(A, lda, a_base + 16 * i + r, k);
-#pragma unroll
-        for (int j = 0; j < NBT; ++j) b[j] = ldfrag<BM>(B, ldb, b_base + 16 * j + r, k);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int i = 0; i < NA; ++i)
-#pragma unroll
-                for (int j = 0; j < NBT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
-    }
-}
 
 template <int NA, int NBT>
 __device__ __forceinline__ void zero_acc(f32x4 (&acc)[NA][NBT]) {
@@ -64,53 +34,145 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[NA][NBT]) {
         for (int j = 0; j < NBT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// E (1, 2 or 4) consecutive floats with ONE load
+template <int E>
+__device__ __forceinline__ void ldv(const float* p, float (&v)[E]) {
+    if constexpr (E == 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    } else if constexpr (E == 2) {
+        const f32x2 t = *reinterpret_cast<const f32x2*>(p);
+        v[0] = t[0]; v[1] = t[1];
+    } else {
+        v[0] = *p;
+    }
+}
+
+// NT (2, 4, 5 or 6) column tiles starting at p (16-float aligned columns) for lane index r:
+//   tiles 0..3 through one 16-B read (tile t = column 4 r + t), the rest through an 8-B / 4-B read at +64
+template <int NT>
+__device__ __forceinline__ void ld_tiles(const float* p, int r, float (&v)[NT]) {
+    if constexpr (NT == 2) {
+        float t[2];
+        ldv<2>(p + 2 * r, t);
+        v[0] = t[0]; v[1] = t[1];
+    } else {
+        float t[4];
+        ldv<4>(p + 4 * r, t);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = t[e];
+        if constexpr (NT == 5) {
+            v[4] = p[64 + r];
+        } else if constexpr (NT == 6) {
+            float u[2];
+            ldv<2>(p + 64 + 2 * r, u);
+            v[4] = u[0]; v[5] = u[1];
+        }
+    }
+}
+// column (relative to p) that tile t of ld_tiles<NT> holds for lane index j
+__host__ __device__ inline int tile_col(int NT, int t, int j) {
+    if (NT == 2) return 2 * j + t;
+    if (t < 4) return 4 * j + t;
+    return NT == 5 ? 64 + j : 64 + 2 * j + (t - 4);
+}
+
+// acc[ea][eb] += sum_s A[s][a0 + EA i + ea] * B[s][b0 + EB j + eb]  (s = 0 .. 4 ksteps - 1), both operands in LDS,
+// sample-major rows: the "TN" weight-gradient GEMM.  Software-pipelined one k-step ahead.
+template <int EA, int EB>
+__device__ __forceinline__ void tn_block(const float* A, int lda, int a0, const float* B, int ldb, int b0, int ksteps,
+                                          f32x4 (&acc)[EA][EB], int lane) {
+    const int r = lane & 15, kq = lane >> 4;
+    const float* ap = A + kq * lda + a0 + EA * r;
+    const float* bp = B + kq * ldb + b0 + EB * r;
+    float a[EA], b[EB];
+    ldv<EA>(ap, a);
+    ldv<EB>(bp, b);
+#pragma unroll 2
+    for (int t = 0; t < ksteps; ++t) {
+        float an[EA], bn[EB];
+        const int tn = t + 1 < ksteps ? t + 1 : t;
+        ldv<EA>(ap + 4 * tn * lda, an);
+        ldv<EB>(bp + 4 * tn * ldb, bn);
+#pragma unroll
+        for (int ea = 0; ea < EA; ++ea)
+#pragma unroll
+            for (int eb = 0; eb < EB; ++eb)
+                acc[ea][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ea], b[eb], acc[ea][eb], 0, 0, 0);
+#pragma unroll
+        for (int ea = 0; ea < EA; ++ea) a[ea] = an[ea];
+#pragma unroll
+        for (int eb = 0; eb < EB; ++eb) b[eb] = bn[eb];
+    }
+}
+
 struct BwdLds {
     int sv, sx, sh, sf;
-    int offV, offX, offH1, offH2, offF, offDo, offInfo, offPre, total;
-    int rg;      // 1: V does not fit next to X, H1, H2 -> it shares the H1 | H2 space and is gathered a second time
+    int offV, offH, offX, offF, offDo, offC, offPre, total;
+    int wide;    // 1: a V tile does not fit next to the rest -> it is loaded late, over the dZ1 | H space
 };
 __host__ __device__ inline BwdLds bwd_lds(const TfShade& S) {
     BwdLds L;
     L.sv = kpad16(S.n_app_total) + 4;
     L.sx = kpad16(S.in_c) + 4;
     L.sh = S.feature_c + 4;
-    L.sf = 36;                       // feat copy / dfeat rows (<= 32 used)
-    L.rg = 0;
-    L.offV = 0;
-    L.offX = L.offV + M * L.sv;
-    L.offH1 = L.offX + M * L.sx;
-    L.offH2 = L.offH1 + M * L.sh;
-    L.offF = L.offH2;                // carved from the H2 region, which is free once dZ1 exists
-    L.offDo = L.offH2 + M * L.sh;
-    if ((size_t)(L.offDo + M * 12 + 80) * sizeof(float) > 160 * 1024) {
-        // Wide appearance bases (e.g. TensorCP [96]/[288] at featureC 128): V is only needed before the MLP (basis ->
-        // feat) and after it (dB, dV), so it takes the H1 | H2 space (plus what it needs beyond) and the kernel
-        // gathers it again once dX is done; feat copy / dfeat rows move out of its way.
-        L.rg = 1;
-        L.offX = 0;
-        L.offH1 = L.offX + M * L.sx;
-        L.offH2 = L.offH1 + M * L.sh;
-        L.offV = L.offH1;
-        const int end_v = L.offV + M * L.sv, end_h = L.offH2 + M * L.sh;
-        L.offF = end_v > end_h ? end_v : end_h;
-        L.offDo = L.offF + 2 * M * L.sf;
+    L.sf = 36;                       // dfeat rows (<= 32 used)
+    const int hreg = M * (2 * L.sh > L.sx ? 2 * L.sh : L.sx);      // H1 | H2, later dX
+    const int consts = 5 * S.feature_c + 8;                         // w3 (3 F), b1, b2, reduction scratch
+    for (L.wide = 0; L.wide < 2; ++L.wide) {
+        const int vreg = M * (L.wide || L.sh > L.sv ? L.sh : L.sv);   // dZ1, later V (narrow)
+        L.offV = 0;
+        L.offH = vreg;
+        L.offX = L.offH + hreg;
+        L.offF = L.offX + M * L.sx;
+        L.offDo = L.offF + M * L.sf;
+        L.offC = L.offDo + M * 4;
+        L.offPre = L.offC + consts;
+        L.total = L.offPre + 80;
+        if ((size_t)L.total * sizeof(float) <= 160 * 1024) break;
     }
-    L.offInfo = L.offDo + M * 4;
-    L.offPre = L.offInfo + M * 8;
-    L.total = L.offPre + 80;
+    if (L.wide > 1) L.wide = 1;
     return L;
 }
+__host__ __device__ inline bool bwd_lds_ok(const TfShade& S, const BwdLds& L) {
+    if ((size_t)L.total * sizeof(float) > 160 * 1024) return false;
+    return !L.wide || M * L.sv <= L.offF;       // a wide V tile spans the dZ1, H and X regions
+}
 
-// floats of one workgroup's weight-gradient slab: dW2 | dW1 | dB tiles of 256 floats each
+// ---- weight-gradient tiles (16x16 accumulator fragments) and where their elements belong --------------------
+// Per workgroup slab: [dW2 tiles | dW1 tiles | dB tiles], 256 floats each in fragment order [lane][4].
+struct WTiles {
+    int FC, EA2, EB2, EA1, NTW, NB, ktB;
+    int n2, n1, nb;
+};
+__host__ __device__ inline WTiles wtiles(const TfShade& S, int ntw) {
+    WTiles T;
+    T.FC = S.feature_c;
+    T.EA2 = S.feature_c / 32;      // dW2: A block = FC/2 columns -> EA2 = FC/32 elements per lane (4 | 2)
+    T.EB2 = S.feature_c / 64;      //      B block = FC/4 columns (2 | 1)
+    T.EA1 = S.feature_c / 64;      // dW1: A block = FC/4 columns (2 | 1)
+    T.NTW = ntw;                   //      column tiles per wave (half of the k tiles of layer 1)
+    T.NB = (S.app_dim + 15) / 16;
+    T.ktB = kpad16(S.n_app_total) / 16;
+    T.n2 = 8 * T.EA2 * T.EB2;
+    T.n1 = 8 * T.EA1 * T.NTW;
+    T.nb = T.NB * T.ktB;
+    return T;
+}
+__host__ __device__ inline int ntw_of(int kt1) {      // compile-time variants: 2, 4, 5, 6 tiles per wave
+    const int h = (kt1 + 1) / 2;
+    return h <= 2 ? 2 : (h <= 4 ? 4 : h);
+}
 __host__ __device__ inline size_t wslab_floats(const TfShade& S) {
-    const int FT = S.feature_c / 16, kt1 = kpad16(S.in_c) / 16, NB = (S.app_dim + 15) / 16, ktB = kpad16(S.n_app_total) / 16;
-    return (size_t)(FT * FT + FT * kt1 + NB * ktB) * 256;
+    const WTiles T = wtiles(S, ntw_of(kpad16(S.in_c) / 16));
+    return (size_t)(T.n2 + T.n1 + T.nb) * 256;
 }
 
 // The packed sample list is cut EVENLY over the persistent workgroups: workgroup w owns samples [w q, (w+1) q) of the
-// shards' concatenation, q = max(64, ceil(S / workgroups)), and walks them in chunks of <= 64.  (Whole 64-sample tiles
-// dealt round-robin leave most workgroups one tile short of the busiest: at config 2, 1281-1288 tiles on 256
-// workgroups are 6 rounds instead of 5.03.)  A chunk may straddle a shard boundary, so it has two pieces.
+// shards' concatenation, q = max(64, ceil(S / workgroups)), and walks them in chunks of <= 64.  A chunk may straddle
+// a shard boundary, so it has two pieces.
 struct Chunk {
     int s0, n0, s1, n1;      // packed positions / lengths of the two pieces (n1 may be 0)
     __device__ __forceinline__ int n() const { return n0 + n1; }
@@ -120,13 +182,14 @@ __host__ __device__ inline int samples_per_wg(int total, int n_wg) {
     const int q = (total + n_wg - 1) / n_wg;
     return q < M ? M : q;
 }
-// spre: exclusive prefix of the shards' sample counts (TF_N_SHARDS + 1 entries); v in [0, v_end)
+// spre: exclusive prefix of the shards' sample counts (TF_N_SHARDS + 1 entries); v in [0, v_end).  Called by whole waves:
+// lane k looks at shard k and a ballot finds the last shard starting at or before v (one LDS read per lane; a 63-step
+// unrolled scan keeps 63 registers live).
 __device__ __forceinline__ bool locate_chunk(const TileSrc& src, const int* spre, int v, int v_end, Chunk& c) {
     c.s0 = c.n0 = c.s1 = c.n1 = 0;
     if (v >= v_end) return false;
-    int g = 0;
-#pragma unroll
-    for (int k = 1; k < TF_N_SHARDS; ++k) g = spre[k] <= v ? k : g;      // last shard starting at or before v
+    static_assert(TF_N_SHARDS == 64, "one shard per lane");
+    const int g = __builtin_popcountll(__ballot(spre[threadIdx.x & 63] <= v)) - 1;      // spre[0] = 0 <= v
     const int want = min(M, v_end - v);
     c.s0 = g * src.seg_cap + (v - spre[g]);
     c.n0 = min(want, spre[g + 1] - v);
@@ -141,55 +204,78 @@ __device__ __forceinline__ bool locate_chunk(const TileSrc& src, const int* spre
     return true;
 }
 
-// FT = feature_c/16 hidden feature tiles (4 or 8), NB = ceil(app_dim/16) (1..2), KT1 = upper bound of the first
-// layer's k tiles kept in registers.  512 threads = 8 waves = 2 per SIMD (256 registers each, no scratch:
-// kernels that spill cannot be replayed from a hipGraph on this stack).
-// Wave w: feature tile ft = w % FT, sample group sg = w / FT (SG = 8/FT groups of NSW = 4/SG sample tiles).
-template <int FT, int NB, int KT1, bool RG>
+// Global -> LDS without registers (global_load_lds_dwordx4): the 64 x (4 * sq)-float row image at `dst` is filled in
+// 1-KiB pieces (one wave instruction: lane l lands at piece base + 16 l bytes); row r < n comes from src + at(r) * w
+// floats, w = 4 wq <= 4 sq data floats per row.  Pad quads and rows >= n are left alone (EXEC-masked lanes do not
+// write): callers keep stale-but-finite data there.  Asynchronous: the issuing wave's vmcnt covers it.
+template <typename AtFn>
+__device__ __forceinline__ void dma_rows(const float* __restrict__ src, int wq, float* dst, int sq, float inv_sq, int n,
+                                         int wave, int lane, AtFn at) {
+    const int pieces = sq;             // 64 rows * sq quads / 64 lanes
+    for (int p = wave; p < pieces; p += 8) {
+        const int q = p * 64 + lane;
+        int row, c4;
+        row_quad(q, sq, inv_sq, row, c4);
+        if (row < n && c4 < wq)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + at(row) * (size_t)(4 * wq) + 4 * c4),
+                                             (__attribute__((address_space(3))) void*)(dst + p * 256), 16, 0, 0);
+    }
+}
+
+// FT = feature_c/16 hidden feature tiles (4 or 8), NB = ceil(app_dim/16) (1..2), NTW = layer-1 k tiles per wave half
+// (2, 4, 5, 6 <-> up to 4, 8, 10, 12 k tiles).  WIDE: see BwdLds.  512 threads = 8 waves = 2 per SIMD.
+// Wave w: hidden feature tile ft = w % FT, sample group sg = w / FT (SG = 8/FT groups of NSW = 4/SG sample tiles).
+template <int FT, int NB, int NTW, bool WIDE>
 __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S, const TileSrc src,
                                                                  const float* __restrict__ grad_rgb,
                                                                  const TfShadeGrads G) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NT = 512, NW = 8, SG = NW / FT, NSW = 4 / SG, NW2 = FT / SG, KT1S = KT1 / SG;
+    constexpr int NT = 512, NW = 8, SG = NW / FT, NSW = 4 / SG;
+    constexpr int FCc = 16 * FT, EA2 = FCc / 32, EB2 = FCc / 64, EA1 = FCc / 64;
+#ifndef TF_KTBW
+#define TF_KTBW 3
+#endif
+    constexpr int KTBW = TF_KTBW;          // dB: column tiles wave, wave + 8, wave + 16 (n_app_total <= 384)
     const BwdLds L = bwd_lds(S);
+    float* DZ1 = lds + L.offV;            // dZ1 [64][sh]; later V [64][sv]
     float* V = lds + L.offV;
-    float* X = lds + L.offX;
-    float* H1 = lds + L.offH1;
-    float* H2 = lds + L.offH2;
-    float* Fs = lds + L.offF;             // feat copy   [64][sf]
-    float* Fd = Fs + M * L.sf;            // dfeat       [64][sf]
+    float* H1 = lds + L.offH;             // [64][sh]
+    float* H2 = H1 + M * L.sh;            // [64][sh]; dZ2 in place
+    float* DX = lds + L.offH;             // dX [64][sx] over H1 | H2
+    float* X = lds + L.offX;              // [64][sx]
+    float* Fd = lds + L.offF;             // dfeat [64][sf]
     float* dO = lds + L.offDo;            // [64][4]
-    int* iray = reinterpret_cast<int*>(lds + L.offInfo);
-    float* ixyz = lds + L.offInfo + M;
-    float* iview = lds + L.offInfo + 4 * M;
+    float* cw3 = lds + L.offC;            // [3][FC]
+    float* cb1 = cw3 + 3 * FCc;
+    float* cb2 = cb1 + FCc;
+    float* cred = cb2 + FCc;              // [8] reduction scratch
     int* pre = reinterpret_cast<int*>(lds + L.offPre);
-    const int tid = threadIdx.x;
-    const int FC = S.feature_c, kp1 = kpad16(S.in_c), kt1 = kp1 / 16, kpB = kpad16(S.n_app_total), ktB = kpB / 16;
+    const int tid0 = threadIdx.x;
+    const int kp1 = kpad16(S.in_c), kt1 = kp1 / 16, kpB = kpad16(S.n_app_total), ktB = kpB / 16;
+    const int xq4 = kp1 / 4, nat = S.n_app_total, vq4 = nat >> 2;
+    const float inv_xq4 = 1.f / (float)xq4, inv_vq4 = 1.f / (float)(vq4 > 0 ? vq4 : 1);
+    const bool v_vec = (nat & 3) == 0;            // V / dV rows are 16-B aligned
+    const float* __restrict__ xs = G.x_saved;
+    float* __restrict__ dv = G.dv_out;            // V rows on entry, dL/dV rows on exit
 
-    // ---- weight-gradient slab of this workgroup (fragment order: [tile][lane][4]) and the few scalars that
-    // do live in registers across tiles
-    float* slabW2 = G.wslab + (size_t)blockIdx.x * wslab_floats(S);
-    float* slabW1 = slabW2 + FT * FT * 256;
-    float* slabB = slabW1 + FT * kt1 * 256;
+    // ---- slab of this workgroup and the register-resident accumulators
+    const WTiles T = wtiles(S, NTW);
+    float* slab = G.wslab + (size_t)blockIdx.x * ((size_t)(T.n2 + T.n1 + T.nb) * 256);
     bool first = true;
-    float aW3[3] = {0.f, 0.f, 0.f}, ab2 = 0.f, ab1 = 0.f, ab3 = 0.f;
-    // The weight-gradient GEMMs (dW2, dW1, dB: sample index = MFMA k dimension) accumulate in registers across the
-    // tiles of this workgroup — 104 VGPRs per lane — and reach the workgroup's slab once, at the end.  (Variants
-    // measured: all three through per-tile slab round trips 411 us, dW1 alone through the slab 402 us, none 392 us;
-    // fetching a phase's weight fragments ahead of its MFMA loop on top of this does not fit the register file.)
-    f32x4 aW2[1][NW2];
+    f32x4 aW2[EA2][EB2];
     zero_acc(aW2);
-    f32x4 aW1[KT1S];                 // dW1: k tiles my_sg, my_sg + SG, ... of feature tile my_ft
+    f32x4 aW1[EA1][NTW];
+    zero_acc(aW1);
+    f32x4 aB[KTBW][NB];
+    zero_acc(aB);
+    float aW3[3][4], ab2[4], ab1[4], ab3 = 0.f;
 #pragma unroll
-    for (int q = 0; q < KT1S; ++q) aW1[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    constexpr int KTBW = 3;          // dB: column tiles wave, wave + 8, wave + 16 (n_app_total <= 384)
-    f32x4 aB[KTBW][NB][1];
-#pragma unroll
-    for (int k = 0; k < KTBW; ++k)
-#pragma unroll
-        for (int i = 0; i < NB; ++i) aB[k][i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int e = 0; e < 4; ++e) {
+        aW3[0][e] = aW3[1][e] = aW3[2][e] = 0.f;
+        ab2[e] = ab1[e] = 0.f;
+    }
 
-    if (tid == 0) {
+    if (tid0 == 0) {
         int run = 0;
         for (int g = 0; g < TF_N_SHARDS; ++g) {
             pre[g] = run;
@@ -197,28 +283,42 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         }
         pre[TF_N_SHARDS] = run;
     }
+    for (int i = tid0; i < 3 * FCc; i += NT) cw3[i] = S.w3[i];
+    if (tid0 < FCc) {
+        cb1[tid0] = S.b1[tid0];
+        cb2[tid0] = S.b2[tid0];
+    }
     __syncthreads();
     const int q_wg = samples_per_wg(pre[TF_N_SHARDS], (int)gridDim.x);
     const int v_end = min(pre[TF_N_SHARDS], ((int)blockIdx.x + 1) * q_wg);
 
-    // per-sample tile info of thread tid < 64, loaded for the NEXT chunk while the current one is processed
-    int nx_ray = 0;
-    float nx_x[3] = {0.f, 0.f, 0.f}, nx_v[3] = {0.f, 0.f, 0.f};
-    auto fetch_info = [&](const Chunk& ck, int tid) {   // tid passed in: the tile loop hands its opaque copy
-        nx_ray = 0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) nx_x[a] = nx_v[a] = 0.f;
-        if (tid < ck.n()) {
-            const size_t s = ck.at(tid);
-            nx_x[0] = src.app_xyz[s * 3]; nx_x[1] = src.app_xyz[s * 3 + 1]; nx_x[2] = src.app_xyz[s * 3 + 2];
-            nx_ray = src.app_ray[s];
-            const float* rp = src.rays + (size_t)nx_ray * 6 + 3;
-            nx_v[0] = rp[0]; nx_v[1] = rp[1]; nx_v[2] = rp[2];
+    // ---- operands of the NEXT chunk, requested while the current one is processed: the X rows travel global -> LDS
+    // by DMA (no registers); thread (sample tid>>2, channel tid&3) holds dL/dc and the forward's colour
+    const int sxq = L.sx >> 2, svq = L.sv >> 2;
+    const float inv_sxq = 1.f / (float)sxq, inv_svq = 1.f / (float)svq;
+    float n_g = 0.f, n_c = 0.f;
+    auto fetch_x = [&](const Chunk& ck, int tid, bool dma) {
+        const int n = ck.n();
+        if (dma)
+            dma_rows(xs, xq4, X, sxq, inv_sxq, n, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63,
+                     [&](int r) { return ck.at(r); });
+        n_g = n_c = 0.f;
+        if (tid < 4 * M && (tid & 3) < 3 && (tid >> 2) < n) {
+            const size_t p = ck.at(tid >> 2) * 3 + (tid & 3);
+            n_g = grad_rgb[p];
+            n_c = G.rgb_fwd[p];
         }
     };
+    // rows past a chunk's end keep what the previous chunk left there: finite, and multiplied by dZ = 0.  Before the
+    // first chunk the X region (and, for the scalar V path, nothing else) must not hold NaN bit patterns
+    for (int i = tid0; i < M * L.sx; i += NT) X[i] = 0.f;
+    if (!WIDE || true) {
+        for (int i = tid0; i < (WIDE ? L.offF : M * L.sv); i += NT) V[i] = 0.f;      // V / dZ1 region likewise
+    }
+    __syncthreads();
     {
         Chunk c1;
-        if (tid < M && locate_chunk(src, pre, (int)blockIdx.x * q_wg, v_end, c1)) fetch_info(c1, tid);
+        if (locate_chunk(src, pre, (int)blockIdx.x * q_wg, v_end, c1)) fetch_x(c1, tid0, true);
     }
 
     TF_T0();
@@ -227,90 +327,33 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         if (!locate_chunk(src, pre, v, v_end, ck)) break;
         const int n = ck.n();
         v += n;
-        // Thread coordinates are re-derived per tile from an opaque copy of the thread id: otherwise the compiler
-        // hoists every phase's per-thread addresses out of the tile loop and runs out of registers (scratch
-        // spills, which also break hipGraph replay on this stack).
+        // Thread coordinates are re-derived per chunk from an opaque copy of the thread id: otherwise the compiler
+        // hoists every phase's per-thread addresses out of the chunk loop and runs out of registers.
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        const int wave = tid >> 6, lane = tid & 63;
+        // the wave index through readfirstlane: wave-dependent branches (which tiles a wave owns) are then scalar branches
+        // instead of per-lane selects over whole accumulator tiles
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
         const int my_ft = wave % FT, my_sg = wave / FT, s_base = my_sg * NSW * 16;
         const int lc = lane & 15, lg = lane >> 4;
 
-        // ---- tile info (fetched one tile ahead: app_ray -> rays is a chain of two global latencies)
-        if (tid < M) {
-            if (src.ndc && tid < n) {   // viewdirs / rays_norm  (tensorBase.py:341-343)
-                float q = nx_v[0] * nx_v[0];
-                q = q + nx_v[1] * nx_v[1];
-                q = q + nx_v[2] * nx_v[2];
-                const float nrm = sqrtf(q);
-                nx_v[0] = nx_v[0] / nrm; nx_v[1] = nx_v[1] / nrm; nx_v[2] = nx_v[2] / nrm;
-            }
-            iray[tid] = nx_ray;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                ixyz[tid * 3 + a] = nx_x[a];
-                iview[tid * 3 + a] = nx_v[a];
-            }
+        // ================= P1: do into LDS; the X rows requested during the previous chunk's P7 have landed =========
+        if (tid < 4 * M) {
+            const float d = n_g * (n_c * (1.f - n_c));       // dL/dc . sigmoid'   (mlp.py:67)
+            dO[tid] = (tid & 3) < 3 ? d : 0.f;
+            ab3 += d;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of X are in LDS
         lds_barrier();
-        {
-            Chunk c1;
-            if (tid < M && locate_chunk(src, pre, v, v_end, c1)) fetch_info(c1, tid);
-        }
+        TF_MARK(0);
 
-        // ================= forward recompute =================
-        {   // gather -> V, 8 lanes per sample
-            const int smp = wave * 8 + (lane >> 3), sub = lane & 7;
-            float u[3] = {ixyz[smp * 3], ixyz[smp * 3 + 1], ixyz[smp * 3 + 2]};
-            float* vrow = V + smp * L.sv;
-            app_products(S, u, sub, vrow, 8);
-            for (int c = S.n_app_total + sub; c < kpB; c += 8) vrow[c] = 0.f;
-        }
-        lds_barrier();
-        TF_MARK(8);
-        if (wave < 4 * NB) {   // basis -> X[:, :app_dim]: one (feature tile, sample tile) per wave
-            const int bf = wave >> 2, bs = wave & 3;
-            f32x4 acc[1][1];
-            zero_acc(acc);
-            mma_block<1, 1>(S.basis, kpB, 16 * bf, V, L.sv, 16 * bs, ktB, acc, lane);
-            const int smp = 16 * bs + lc;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int f = 16 * bf + 4 * lg + e;
-                if (f < S.app_dim) X[smp * L.sx + f] = acc[0][0][e];
-            }
-        }
-        if (tid < M) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a) X[tid * L.sx + S.app_dim + a] = iview[tid * 3 + a];
-        }
-        lds_barrier();
-        TF_MARK(9);
-        {   // PE blocks + zero padding
-            int off = S.app_dim + 3;
-            for (int b = 0; b < S.n_pe; ++b) {
-                const int src_k = S.pe[b].src, F = S.pe[b].freqs;
-                const int D = src_k == TF_SRC_FEAT ? S.app_dim : 3;
-                const float* mk = S.pe[b].mask;
-                const int sx = L.sx;
-                pe_block<NT>(X, L.sx, off, D, F, mk, tid, [&](int smp, int d) {
-                    return src_k == TF_SRC_FEAT ? X[smp * sx + d] : (src_k == TF_SRC_VIEW ? iview[smp * 3 + d] : ixyz[smp * 3 + d]);
-                });
-                off += 2 * D * F;
-            }
-            for (int it = tid; it < M * 16; it += NT) {        // the K padding is < 16 columns
-                const int smp = it >> 4, c = S.in_c + (it & 15);
-                if (c < kp1) X[smp * L.sx + c] = 0.f;
-            }
-        }
-        lds_barrier();
-        TF_MARK(10);
-        {   // layer 1 -> H1
+        // ================= P2: layer 1 -> H1 =================
+        {
             f32x4 acc[1][NSW];
             zero_acc(acc);
             mma_block<1, NSW>(S.w1, kp1, 16 * my_ft, X, L.sx, s_base, kt1, acc, lane);
             const int f = 16 * my_ft + 4 * lg;
-            const f32x4 bias = *reinterpret_cast<const f32x4*>(S.b1 + f);
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(cb1 + f);
 #pragma unroll
             for (int j = 0; j < NSW; ++j) {
                 f32x4 h = acc[0][j] + bias;
@@ -320,161 +363,113 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
             }
         }
         lds_barrier();
-        TF_MARK(11);
-        {   // layer 2 -> H2
-            f32x4 acc[1][NSW];
-            zero_acc(acc);
-            mma_block<1, NSW>(S.w2, kpad16(FC), 16 * my_ft, H1, L.sh, s_base, FC / 16, acc, lane);
-            const int f = 16 * my_ft + 4 * lg;
-            const f32x4 bias = *reinterpret_cast<const f32x4*>(S.b2 + f);
-#pragma unroll
-            for (int j = 0; j < NSW; ++j) {
-                f32x4 h = acc[0][j] + bias;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = fmaxf(h[e], 0.f);
-                *reinterpret_cast<f32x4*>(H2 + (s_base + 16 * j + lc) * L.sh + f) = h;
-            }
-        }
-        lds_barrier();
-        TF_MARK(12);
-        {   // output layer, sigmoid, do = dL/dc * c (1 - c); 8 lanes per sample
-            const int smp = tid >> 3, sub = tid & 7;
-            const float* h = H2 + smp * L.sh;
-            float o[3] = {0.f, 0.f, 0.f};
-            for (int f = sub * 4; f < FC; f += 32) {
-                const f32x4 hv = *reinterpret_cast<const f32x4*>(h + f);
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(S.w3 + ch * FC + f);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[ch] = fmaf(hv[e], w[e], o[ch]);
-                }
-            }
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                o[ch] = quad_sum(o[ch]);
-                o[ch] += __shfl_xor(o[ch], 4, 64);
-            }
-            if (sub < 3) {
-                const float ov = sub == 0 ? o[0] : (sub == 1 ? o[1] : o[2]);
-                float d = 0.f;
-                if (smp < n) {
-                    const float c = 1.f / (1.f + expf(-(ov + S.b3[sub])));
-                    d = grad_rgb[ck.at(smp) * 3 + sub] * (c * (1.f - c));
-                }
-                dO[smp * 4 + sub] = d;
-            }
-        }
-        lds_barrier();
-        TF_MARK(0);
-
-        // ================= backward =================
-        const int pf = tid % FC, pslice = tid / FC, pspan = M / (NT / FC);   // per-feature passes: thread -> (f, sample slice)
-        {   // dW3, db3, dZ2 (in place of H2), db2
-            const float w0 = S.w3[pf], w1 = S.w3[FC + pf], w2 = S.w3[2 * FC + pf];
-            for (int s = pslice * pspan; s < (pslice + 1) * pspan; ++s) {
-                const float d0 = dO[s * 4], d1 = dO[s * 4 + 1], d2 = dO[s * 4 + 2];
-                const float h = H2[s * L.sh + pf];
-                aW3[0] = fmaf(d0, h, aW3[0]);
-                aW3[1] = fmaf(d1, h, aW3[1]);
-                aW3[2] = fmaf(d2, h, aW3[2]);
-                const float dz = h > 0.f ? fmaf(d2, w2, fmaf(d1, w1, d0 * w0)) : 0.f;
-                H2[s * L.sh + pf] = dz;
-                ab2 += dz;
-            }
-            if (tid < 3) {
-                float a = 0.f;
-                for (int s = 0; s < M; ++s) a += dO[s * 4 + tid];
-                ab3 += a;
-            }
-        }
-        lds_barrier();
         TF_MARK(1);
-        {   // dW2[f2][f1] += sum_s dZ2[s][f2] H1[s][f1]
-            mma_gen<1, NW2, COL, COL>(H2, L.sh, 16 * my_ft, H1, L.sh, 16 * NW2 * my_sg, M / 16, aW2, lane);
-        }
-        lds_barrier();   // every wave is done reading H1 for dW2
-        TF_MARK(2);
-        {   // dH1[f1][s] = sum_f2 W2[f2][f1] dZ2[s][f2];  dZ1 = dH1 . [H1 > 0] written in place of H1
+
+        // ================= P3: layer 2 -> H2; dW3, dZ2 (in place of H2), db2 in the epilogue =================
+        {
             f32x4 acc[1][NSW];
             zero_acc(acc);
-            mma_block<1, NSW>(S.w2t, FC, 16 * my_ft, H2, L.sh, s_base, FC / 16, acc, lane);
+            mma_block<1, NSW>(S.w2, FCc, 16 * my_ft, H1, L.sh, s_base, FCc / 16, acc, lane);
             const int f = 16 * my_ft + 4 * lg;
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(cb2 + f);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(cw3 + f);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(cw3 + FCc + f);
+            const f32x4 w2 = *reinterpret_cast<const f32x4*>(cw3 + 2 * FCc + f);
 #pragma unroll
             for (int j = 0; j < NSW; ++j) {
-                float* hp = H1 + (s_base + 16 * j + lc) * L.sh + f;
-                const f32x4 h = *reinterpret_cast<const f32x4*>(hp);
+                const int s = s_base + 16 * j + lc;
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dO + 4 * s);
                 f32x4 dz;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dz[e] = h[e] > 0.f ? acc[0][j][e] : 0.f;
-                *reinterpret_cast<f32x4*>(hp) = dz;
-            }
-        }
-        lds_barrier();
-        TF_MARK(3);
-        {   // db1 += column sums of dZ1
-            float a = 0.f;
-            for (int s = pslice * pspan; s < (pslice + 1) * pspan; ++s) a += H1[s * L.sh + pf];
-            ab1 += a;
-        }
-        // dW1[f][k] += sum_s dZ1[s][f] X[s][k]: dZ1 fragments are read once per k-group and reused for every k tile
-        // this wave owns (k tiles my_sg, my_sg + SG, ...); the accumulators live in registers across tiles
-#pragma unroll 1
-        for (int kg = 0; kg < M / 16; ++kg) {
-            const int ks = 16 * kg + 4 * lg;
-            const f32x4 a = ldfrag<COL>(H1, L.sh, 16 * my_ft + lc, ks);
-            // GQ k tiles at a time: their MFMA chains interleave (a chain of four dependent MFMAs per tile would wait
-            // on its own accumulator)
-            constexpr int GQ = KT1S % 4 == 0 ? 4 : 2;
-            static_assert(KT1S % GQ == 0, "k tiles per wave come in groups");
-#pragma unroll
-            for (int q0 = 0; q0 < KT1S; q0 += GQ) {
-                f32x4 b[GQ];
-#pragma unroll
-                for (int g = 0; g < GQ; ++g) {
-                    const int j = my_sg + SG * (q0 + g);
-                    b[g] = j < kt1 ? ldfrag<COL>(X, L.sx, 16 * j + lc, ks) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int e = 0; e < 4; ++e) {
+                    const float h = fmaxf(acc[0][j][e] + bias[e], 0.f);
+                    aW3[0][e] = fmaf(d[0], h, aW3[0][e]);
+                    aW3[1][e] = fmaf(d[1], h, aW3[1][e]);
+                    aW3[2][e] = fmaf(d[2], h, aW3[2][e]);
+                    dz[e] = h > 0.f ? fmaf(d[2], w2[e], fmaf(d[1], w1[e], d[0] * w0[e])) : 0.f;
+                    ab2[e] += dz[e];
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int g = 0; g < GQ; ++g)
-                        if (my_sg + SG * (q0 + g) < kt1)
-                            aW1[q0 + g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[g][e], aW1[q0 + g], 0, 0, 0);
+                *reinterpret_cast<f32x4*>(H2 + s * L.sh + f) = dz;
             }
         }
-        lds_barrier();   // dW1 finished reading X; the H2 region (dZ2) is free
-        TF_MARK(4);
-        for (int smp = wave; smp < M; smp += NW)             // feat copy for the PE derivative
-            if (lane < S.app_dim) Fs[smp * L.sf + lane] = X[smp * L.sx + lane];
         lds_barrier();
-        // dX[k][s] = sum_f W1[f][k] dZ1[s][f], written in place of X.  Work items are (k tile, pair of sample tiles):
-        // 2 kt1 items dealt round-robin, so that e.g. 10 k tiles load the 8 waves evenly (whole k tiles would give two
-        // waves twice the work)
+        TF_MARK(2);
+
+        // ================= P4: dZ1 = (W2^T dZ2) . [H1 > 0] -> DZ1, db1;  dW2 += dZ2^T H1 =================
+        {
+            f32x4 acc[1][NSW];
+            zero_acc(acc);
+            mma_block<1, NSW>(S.w2t, FCc, 16 * my_ft, H2, L.sh, s_base, FCc / 16, acc, lane);
+            const int f = 16 * my_ft + 4 * lg;
+#pragma unroll
+            for (int j = 0; j < NSW; ++j) {
+                const int s = s_base + 16 * j + lc;
+                const f32x4 h = *reinterpret_cast<const f32x4*>(H1 + s * L.sh + f);
+                f32x4 dz;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dz[e] = h[e] > 0.f ? acc[0][j][e] : 0.f;
+                    ab1[e] += dz[e];
+                }
+                *reinterpret_cast<f32x4*>(DZ1 + s * L.sh + f) = dz;
+            }
+            TF_MARK(3);
+            // dW2[f2][f1]: wave -> (f2 block of FC/2, f1 block of FC/4)
+            tn_block<EA2, EB2>(H2, L.sh, (FCc / 2) * (wave >> 2), H1, L.sh, (FCc / 4) * (wave & 3), M / 4, aW2, lane);
+        }
+        lds_barrier();
+        TF_MARK(4);
+
+        // ================= P5: dW1 += dZ1^T X;  dX = W1^T dZ1 -> DX (over H1 | H2) =================
+        {
+            // dW1[f][k]: wave -> (f block of FC/4 columns of dZ1, half of the k tiles of X)
+            const int r = lane & 15, kq = lane >> 4;
+            const float* ap = DZ1 + kq * L.sh + (FCc / 4) * (wave >> 1) + EA1 * r;
+            const float* bp = X + kq * L.sx + 16 * NTW * (wave & 1);
+            float a[EA1], b[NTW];
+            ldv<EA1>(ap, a);
+            ld_tiles<NTW>(bp, r, b);
+#pragma unroll 2
+            for (int t = 0; t < M / 4; ++t) {
+                float an[EA1], bn[NTW];
+                const int tn = t + 1 < M / 4 ? t + 1 : t;
+                ldv<EA1>(ap + 4 * tn * L.sh, an);
+                ld_tiles<NTW>(bp + 4 * tn * L.sx, r, bn);
+#pragma unroll
+                for (int ea = 0; ea < EA1; ++ea)
+#pragma unroll
+                    for (int eb = 0; eb < NTW; ++eb)
+                        aW1[ea][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ea], b[eb], aW1[ea][eb], 0, 0, 0);
+#pragma unroll
+                for (int ea = 0; ea < EA1; ++ea) a[ea] = an[ea];
+#pragma unroll
+                for (int eb = 0; eb < NTW; ++eb) b[eb] = bn[eb];
+            }
+        }
+        TF_MARK(5);
+        // dX[k][s] = sum_f W1[f][k] dZ1[s][f].  Work items are (k tile, pair of sample tiles): 2 kt1 items dealt
+        // round-robin (waves w and w + 4 share a SIMD, so 2.5 items per wave are 5 per SIMD)
         for (int it = wave; it < 2 * kt1; it += NW) {
             const int kt = it >> 1, sp = it & 1;
             f32x4 acc[1][2];
             zero_acc(acc);
-            mma_block<1, 2>(S.w1t, FC, 16 * kt, H1, L.sh, 32 * sp, FC / 16, acc, lane);
+            mma_block<1, 2>(S.w1t, FCc, 16 * kt, DZ1, L.sh, 32 * sp, FCc / 16, acc, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                *reinterpret_cast<f32x4*>(X + (32 * sp + 16 * j + lc) * L.sx + 16 * kt + 4 * lg) = acc[0][j];
+                *reinterpret_cast<f32x4*>(DX + (32 * sp + 16 * j + lc) * L.sx + 16 * kt + 4 * lg) = acc[0][j];
         }
         lds_barrier();
-        TF_MARK(5);
-        if (RG) {   // V again (its space held H1 / H2 meanwhile); lands while the PE derivative below computes
-            const int smp = wave * 8 + (lane >> 3), sub = lane & 7;
-            float u[3] = {ixyz[smp * 3], ixyz[smp * 3 + 1], ixyz[smp * 3 + 2]};
-            float* vrow = V + smp * L.sv;
-            app_products(S, u, sub, vrow, 8);
-            for (int c = S.n_app_total + sub; c < kpB; c += 8) vrow[c] = 0.f;
-        }
+        TF_MARK(6);
+
+        // ================= P6: dfeat -> Fd;  V -> LDS (over dZ1) =================
+        if (!WIDE && v_vec)      // V rows of this chunk: global -> LDS by DMA, landing behind the dfeat arithmetic
+            dma_rows(dv, vq4, V, svq, inv_svq, n, wave, lane, [&](int r) { return ck.at(r); });
         {   // dfeat = dX[:, :D] + PE'(feat): d/dx [sin(x 2^k) m_s] = cos(.) 2^k m_s,  d/dx [cos(.) m_c] = -sin(.) 2^k m_c
             for (int it = tid; it < M * 16 * NB; it += NT) {
                 const int smp = it / (16 * NB), d = it % (16 * NB);
                 float gsum = 0.f;
                 if (d < S.app_dim) {
-                    const float* dx = X + smp * L.sx;
+                    const float* dx = DX + smp * L.sx;
                     gsum = dx[d];
                     int off = S.app_dim + 3;
                     for (int b = 0; b < S.n_pe; ++b) {
@@ -482,18 +477,27 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                         const int D = S.pe[b].src == TF_SRC_FEAT ? S.app_dim : 3;
                         if (S.pe[b].src == TF_SRC_FEAT) {
                             const float* mk = S.pe[b].mask;
-                            const float v = Fs[smp * L.sf + d];
+                            const float fv = X[smp * L.sx + d];
                             float fr = 1.f;
-                            const bool big = !(ldexpf(fabsf(v), F - 1) < 8192.f);
-                            for (int k = 0; k < F; ++k) {
-                                float sn, cs;
-                                if (__builtin_expect(big, 0)) pe_sincos(v * fr, &sn, &cs);
-                                else pe_sincos_fast(v * fr, &sn, &cs);
-                                const int ci = d * F + k;
-                                const float ms = mk ? mk[ci] : 1.f, mc = mk ? mk[D * F + ci] : 1.f;
-                                gsum += dx[off + ci] * (cs * fr * ms);
-                                gsum -= dx[off + D * F + ci] * (sn * fr * mc);
-                                fr *= 2.f;
+                            const bool big = !(ldexpf(fabsf(fv), F - 1) < 8192.f);
+                            if (!mk) {     // unmasked: X's PE columns ARE sin / cos of these arguments (saved by the forward)
+                                const float* xr = X + smp * L.sx + off;
+                                for (int k = 0; k < F; ++k) {
+                                    const int ci = d * F + k;
+                                    gsum += dx[off + ci] * (xr[D * F + ci] * fr);
+                                    gsum -= dx[off + D * F + ci] * (xr[ci] * fr);
+                                    fr *= 2.f;
+                                }
+                            } else {
+                                for (int k = 0; k < F; ++k) {
+                                    float sn, cs;
+                                    if (__builtin_expect(big, 0)) pe_sincos(fv * fr, &sn, &cs);
+                                    else pe_sincos_fast(fv * fr, &sn, &cs);
+                                    const int ci = d * F + k;
+                                    gsum += dx[off + ci] * (cs * fr * mk[ci]);
+                                    gsum -= dx[off + D * F + ci] * (sn * fr * mk[D * F + ci]);
+                                    fr *= 2.f;
+                                }
                             }
                         }
                         off += 2 * D * F;
@@ -502,77 +506,186 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                 Fd[smp * L.sf + d] = gsum;
             }
         }
-        lds_barrier();
-        // dB[f][c] += sum_s dfeat[s][f] V[s][c]; wave w owns column tiles w, w+8, w+16 (register accumulators)
-#pragma unroll
-        for (int k = 0; k < KTBW; ++k) {
-            const int ct = wave + NW * k;
-            if (ct < ktB) mma_gen<NB, 1, COL, COL>(Fd, L.sf, 0, V, L.sv, 16 * ct, M / 16, aB[k], lane);
+        if (!WIDE && !v_vec) {
+            for (int smp = wave; smp < M; smp += NW)
+                for (int c = lane; c < nat; c += 64) V[smp * L.sv + c] = smp < n ? dv[ck.at(smp) * nat + c] : 0.f;
         }
-        lds_barrier();   // dB finished reading V
-        // dV[c][s] = sum_f B[f][c] dfeat[s][f], written in place of V
-        for (int ct = wave; ct < ktB; ct += NW) {
-            f32x4 acc[1][4];
-            zero_acc(acc);
-            mma_gen<1, 4, COL, ROW>(S.basis, kpB, 16 * ct, Fd, L.sf, 0, NB, acc, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<f32x4*>(V + (16 * j + lc) * L.sv + 16 * ct + 4 * lg) = acc[0][j];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of V are in LDS
+        lds_barrier();
+        if (WIDE) {     // the V tile needs the dZ1 | H space, which dfeat has just finished reading
+            for (int smp = wave; smp < M; smp += NW)
+                for (int c = lane; c < nat; c += 64) V[smp * L.sv + c] = smp < n ? dv[ck.at(smp) * nat + c] : 0.f;
+            lds_barrier();
         }
-        lds_barrier();
-        TF_MARK(6);
-        // hand dL/dV to the scatter stage (tf_binned_scatter for VM, app_direct_scatter_kernel otherwise)
-        for (int smp = wave; smp < n; smp += NW)
-            for (int c = lane; c < S.n_app_total; c += 64)
-                G.dv_out[ck.at(smp) * S.n_app_total + c] = V[smp * L.sv + c];
-        first = false;
-        lds_barrier();
         TF_MARK(7);
+        // operands of the next chunk: its X rows go straight into the X region, which nothing reads any more (a WIDE V
+        // tile lies over it: there the request waits until P7 is done)
+        {
+            Chunk c1;
+            if (locate_chunk(src, pre, v, v_end, c1)) fetch_x(c1, tid, !WIDE);
+            else n_g = n_c = 0.f;
+        }
+
+        // ================= P7: dB += dfeat^T V;  dV = B^T dfeat -> dv_out =================
+#ifndef TF_X_NODB
+        {   // dB[f][c]: A = Fd (NB elements per lane: f = NB i + e), B = V column tiles wave, wave + 8, wave + 16
+            const int r = lane & 15, kq = lane >> 4;
+            const float* ap = Fd + kq * L.sf + NB * r;
+            const float* bp = V + kq * L.sv + 16 * wave + r;
+#pragma unroll 2
+            for (int t = 0; t < M / 4; ++t) {
+                float a[NB];
+                ldv<NB>(ap + 4 * t * L.sf, a);
+#pragma unroll
+                for (int k = 0; k < KTBW; ++k) {
+                    if (wave + NW * k < ktB) {
+                        const float b = bp[4 * t * L.sv + 128 * k];
+#pragma unroll
+                        for (int e = 0; e < NB; ++e)
+                            aB[k][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b, aB[k][e], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#endif
+        TF_MARK(8);
+#ifndef TF_X_NODV
+        {   // dV[s][c] = sum_f B[f][c] dfeat[s][f]: units (group of 4 column tiles | single tile, sample tile), dealt from
+            // the last wave down (the low waves own the extra dB tiles).  A = packed basis rows f (k index), read
+            // 4 columns per lane; B = Fd[s][f].  The accumulators go straight to dv_out.
+            const int r = lane & 15, kq = lane >> 4;
+            const int g4 = ktB >> 2, n_units = 4 * (g4 + (ktB & 3));
+            for (int u = NW - 1 - wave; u < n_units; u += NW) {
+                const int st = u & 3, grp = u >> 2;
+                const float* bp = Fd + (16 * st + r) * L.sf + kq;
+                const int s = 16 * st + lc;
+                if (grp < g4) {
+                    const int cb = 64 * grp;
+                    f32x4 acc[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    const float* ap = S.basis + (size_t)kq * kpB + cb + 4 * r;
+#pragma unroll
+                    for (int t = 0; t < 4 * NB; ++t) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(ap + (size_t)4 * t * kpB);
+                        const float b = bp[4 * t];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b, acc[e], 0, 0, 0);
+                    }
+                    if (s < n) {     // element (e, reg): column cb + 4 (4 lg + reg) + e
+                        float* o = dv + ck.at(s) * nat;
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int c = cb + 16 * lg + 4 * reg;
+                            if (v_vec && c + 3 < nat) {
+                                *reinterpret_cast<f32x4*>(o + c) = (f32x4){acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]};
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (c + e < nat) o[c + e] = acc[e][reg];
+                            }
+                        }
+                    }
+                } else {
+                    const int cb = 64 * g4 + 16 * (grp - g4);
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    const float* ap = S.basis + (size_t)kq * kpB + cb + r;
+#pragma unroll
+                    for (int t = 0; t < 4 * NB; ++t)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(size_t)4 * t * kpB], bp[4 * t], acc, 0, 0, 0);
+                    if (s < n) {     // element reg: column cb + 4 lg + reg
+                        float* o = dv + ck.at(s) * nat;
+                        const int c = cb + 4 * lg;
+                        if (v_vec && c + 3 < nat) {
+                            *reinterpret_cast<f32x4*>(o + c) = acc;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (c + e < nat) o[c + e] = acc[e];
+                        }
+                    }
+                }
+            }
+        }
+#endif
+        first = false;
+        TF_MARK(9);
+        // no barrier here: the next chunk's P1 writes X and dO only, which nothing in P7 reads (a WIDE V tile lies over X)
+        if (WIDE) {
+            lds_barrier();
+            Chunk c1;
+            if (locate_chunk(src, pre, v, v_end, c1))
+                dma_rows(xs, xq4, X, sxq, inv_sxq, c1.n(), wave, lane, [&](int r) { return c1.at(r); });
+        }
     }
     TF_FLUSH();
 
-    if (!first) {      // this workgroup owned at least one tile: its register-resident weight gradients go to the slab
-        int tid3 = threadIdx.x;
-        asm volatile("" : "+v"(tid3));
-        const int wave = tid3 >> 6, lane = tid3 & 63, my_ft = wave % FT, my_sg = wave / FT;
+    int tid3 = threadIdx.x;
+    asm volatile("" : "+v"(tid3));
+    if (!first) {      // this workgroup owned at least one chunk: its register-resident weight gradients go to the slab
+        const int wave = __builtin_amdgcn_readfirstlane(tid3 >> 6), lane = tid3 & 63;
+        float* sl = slab;
 #pragma unroll
-        for (int j = 0; j < NW2; ++j)
-            *reinterpret_cast<f32x4*>(slabW2 + ((size_t)(my_ft * FT + NW2 * my_sg + j) * 64 + lane) * 4) = aW2[0][j];
+        for (int ea = 0; ea < EA2; ++ea)
 #pragma unroll
-        for (int q = 0; q < KT1S; ++q) {
-            const int j = my_sg + SG * q;
-            if (j < kt1) *reinterpret_cast<f32x4*>(slabW1 + ((size_t)(my_ft * kt1 + j) * 64 + lane) * 4) = aW1[q];
-        }
+            for (int eb = 0; eb < EB2; ++eb)
+                *reinterpret_cast<f32x4*>(sl + ((size_t)((wave * EA2 + ea) * EB2 + eb) * 64 + lane) * 4) = aW2[ea][eb];
+        sl += (size_t)T.n2 * 256;
+#pragma unroll
+        for (int ea = 0; ea < EA1; ++ea)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+                *reinterpret_cast<f32x4*>(sl + ((size_t)((wave * EA1 + ea) * NTW + t) * 64 + lane) * 4) = aW1[ea][t];
+        sl += (size_t)T.n1 * 256;
 #pragma unroll
         for (int k = 0; k < KTBW; ++k) {
             const int ct = wave + NW * k;
             if (ct < ktB) {
 #pragma unroll
-                for (int i = 0; i < NB; ++i)
-                    *reinterpret_cast<f32x4*>(slabB + ((size_t)(i * ktB + ct) * 64 + lane) * 4) = aB[k][i][0];
+                for (int e = 0; e < NB; ++e)
+                    *reinterpret_cast<f32x4*>(sl + ((size_t)(e * ktB + ct) * 64 + lane) * 4) = aB[k][e];
             }
         }
     }
-    // ================= the per-feature scalars (the GEMM gradients are in the slab) =================
+    // ================= the per-feature vectors: reduce over the 16 sample lanes, then one atomic per feature ===========
     {
-        int tid2 = threadIdx.x;
-        asm volatile("" : "+v"(tid2));      // keeps these addresses from being computed (and held) before the tile loop
-        const int pf = tid2 % FC;
-        atomicAdd(G.w3 + pf, aW3[0]);
-        atomicAdd(G.w3 + FC + pf, aW3[1]);
-        atomicAdd(G.w3 + 2 * FC + pf, aW3[2]);
-        atomicAdd(G.b2 + pf, ab2);
-        atomicAdd(G.b1 + pf, ab1);
-        if (tid2 < 3) atomicAdd(G.b3 + tid2, ab3);
+        const int wave = tid3 >> 6, lane = tid3 & 63, lc = lane & 15, lg = lane >> 4;
+        const int f = 16 * (wave % FT) + 4 * lg;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v0 = aW3[0][e], v1 = aW3[1][e], v2 = aW3[2][e], v3 = ab2[e], v4 = ab1[e];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                v0 += __shfl_xor(v0, o, 64);
+                v1 += __shfl_xor(v1, o, 64);
+                v2 += __shfl_xor(v2, o, 64);
+                v3 += __shfl_xor(v3, o, 64);
+                v4 += __shfl_xor(v4, o, 64);
+            }
+            if (lc == 0) {
+                atomicAdd(G.w3 + f + e, v0);
+                atomicAdd(G.w3 + FCc + f + e, v1);
+                atomicAdd(G.w3 + 2 * FCc + f + e, v2);
+                atomicAdd(G.b2 + f + e, v3);
+                atomicAdd(G.b1 + f + e, v4);
+            }
+        }
+        // db3: thread (sample, channel) sums over its chunks -> LDS -> one atomic per channel
+        __syncthreads();
+        if (tid3 < 4) cred[tid3] = 0.f;
+        __syncthreads();
+        if (tid3 < 4 * M && (tid3 & 3) < 3) atomicAdd(cred + (tid3 & 3), ab3);
+        __syncthreads();
+        if (tid3 < 3) atomicAdd(G.b3 + tid3, cred[tid3]);
     }
 }
 
 // Sums the workgroups' weight-gradient slabs (fragment order) into the row-major gradient matrices.  Workgroup b
-// wrote its slab iff it owned samples, i.e. b * samples_per_wg < total.  One workgroup per 16x16 tile (256 floats
-// = 64 float4 columns): thread (group g = tid>>6, lane) adds the slabs b = g, g+4, ... with 16-B loads, the four
-// groups meet in LDS.
+// wrote its slab iff it owned samples, i.e. b * samples_per_wg < total.  One workgroup per 16x16 fragment tile (256
+// floats = 64 float4): thread (group g = tid>>6, lane) adds the slabs b = g, g+4, ... with 16-B loads, the four
+// groups meet in LDS; the element's (row, column) is recovered from the tile's place in the slab (see WTiles).
 __global__ __launch_bounds__(256) void wslab_reduce_kernel(const TfShade S, const int* __restrict__ counters,
-                                                           int n_wg, const TfShadeGrads G) {
+                                                           int n_wg, int ntw, const TfShadeGrads G) {
     __shared__ int s_active;
     __shared__ f32x4 part[4][64];
     const int tid = threadIdx.x, grp = tid >> 6, lane = tid & 63;
@@ -584,8 +697,8 @@ __global__ __launch_bounds__(256) void wslab_reduce_kernel(const TfShade S, cons
     }
     __syncthreads();
     const int active = s_active;
-    const int FT = S.feature_c / 16, kt1 = kpad16(S.in_c) / 16, ktB = kpad16(S.n_app_total) / 16;
-    const size_t stride = wslab_floats(S);
+    const WTiles T = wtiles(S, ntw);
+    const size_t stride = (size_t)(T.n2 + T.n1 + T.nb) * 256;
     const int tile = blockIdx.x;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
     const float* src = G.wslab + (size_t)tile * 256 + lane * 4;
@@ -595,17 +708,21 @@ __global__ __launch_bounds__(256) void wslab_reduce_kernel(const TfShade S, cons
     __syncthreads();
     if (grp != 0) return;
     a = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-    const int c = lane & 15;
+    const int j = lane & 15;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const int r = 4 * (lane >> 4) + e;
-        if (tile < FT * FT) {
-            G.w2[(size_t)(16 * (tile / FT) + r) * S.feature_c + 16 * (tile % FT) + c] = a[e];
-        } else if (tile < FT * FT + FT * kt1) {
-            const int t2 = tile - FT * FT, k = 16 * (t2 % kt1) + c;
-            if (k < S.in_c) G.w1[(size_t)(16 * (t2 / kt1) + r) * S.in_c + k] = a[e];
-        } else {
-            const int t3 = tile - FT * FT - FT * kt1, f = 16 * (t3 / ktB) + r, cc = 16 * (t3 % ktB) + c;
+        const int i = 4 * (lane >> 4) + e;
+        if (tile < T.n2) {            // dW2 tile (wave, ea, eb)
+            const int eb = tile % T.EB2, ea = (tile / T.EB2) % T.EA2, w = tile / (T.EA2 * T.EB2);
+            const int f2 = (T.FC / 2) * (w >> 2) + T.EA2 * i + ea, f1 = (T.FC / 4) * (w & 3) + T.EB2 * j + eb;
+            G.w2[(size_t)f2 * T.FC + f1] = a[e];
+        } else if (tile < T.n2 + T.n1) {   // dW1 tile (wave, ea, t)
+            const int t2 = tile - T.n2, t = t2 % T.NTW, ea = (t2 / T.NTW) % T.EA1, w = t2 / (T.NTW * T.EA1);
+            const int f = (T.FC / 4) * (w >> 1) + T.EA1 * i + ea, k = 16 * T.NTW * (w & 1) + tile_col(T.NTW, t, j);
+            if (k < S.in_c) G.w1[(size_t)f * S.in_c + k] = a[e];
+        } else {                      // dB tile (e_f, column tile)
+            const int t3 = tile - T.n2 - T.n1, ct = t3 % T.ktB, ef = t3 / T.ktB;
+            const int f = T.NB * i + ef, cc = 16 * ct + j;
             if (f < S.app_dim && cc < S.n_app_total) G.basis[(size_t)f * S.n_app_total + cc] = a[e];
         }
     }
@@ -663,20 +780,29 @@ __global__ __launch_bounds__(256) void app_direct_scatter_kernel(const TfShade S
 typedef void (*bwd_fn_t)(const TfShade, const TileSrc, const float*, const TfShadeGrads);
 
 template <int FT, int NB>
-bwd_fn_t pick_kt(int kt1, bool rg) {
-    if (kt1 <= 4) return rg ? shade_backward_kernel<FT, NB, 4, true> : shade_backward_kernel<FT, NB, 4, false>;
-    if (kt1 <= 8) return rg ? shade_backward_kernel<FT, NB, 8, true> : shade_backward_kernel<FT, NB, 8, false>;
-    if (kt1 <= 12) return rg ? shade_backward_kernel<FT, NB, 12, true> : shade_backward_kernel<FT, NB, 12, false>;
+bwd_fn_t pick_ntw(int ntw, bool wide) {
+    switch (ntw) {
+        case 2: return wide ? shade_backward_kernel<FT, NB, 2, true> : shade_backward_kernel<FT, NB, 2, false>;
+        case 4: return wide ? shade_backward_kernel<FT, NB, 4, true> : shade_backward_kernel<FT, NB, 4, false>;
+        case 5: return wide ? shade_backward_kernel<FT, NB, 5, true> : shade_backward_kernel<FT, NB, 5, false>;
+        case 6: return wide ? shade_backward_kernel<FT, NB, 6, true> : shade_backward_kernel<FT, NB, 6, false>;
+    }
     return nullptr;
 }
 
 bwd_fn_t pick_bwd(const TfShade& S) {
+#ifdef TF_ONLY_C2     // compile-time experiments: the benchmark configuration only
+    return shade_backward_kernel<8, 2, 5, false>;
+#else
     const int nb = (S.app_dim + 15) / 16, kt1 = kpad16(S.in_c) / 16;
-    if (S.head != TF_HEAD_MLP || nb > 2 || kpad16(S.n_app_total) / 16 > 24) return nullptr;
-    const bool rg = bwd_lds(S).rg != 0;
-    if (S.feature_c == 64) return nb == 1 ? pick_kt<4, 1>(kt1, rg) : pick_kt<4, 2>(kt1, rg);
-    if (S.feature_c == 128) return nb == 1 ? pick_kt<8, 1>(kt1, rg) : pick_kt<8, 2>(kt1, rg);
+    if (S.head != TF_HEAD_MLP || nb > 2 || kt1 > 12 || kpad16(S.n_app_total) / 16 > 24) return nullptr;
+    const BwdLds L = bwd_lds(S);
+    if (!bwd_lds_ok(S, L)) return nullptr;
+    const int ntw = ntw_of(kt1);
+    if (S.feature_c == 64) return nb == 1 ? pick_ntw<4, 1>(ntw, L.wide) : pick_ntw<4, 2>(ntw, L.wide);
+    if (S.feature_c == 128) return nb == 1 ? pick_ntw<8, 1>(ntw, L.wide) : pick_ntw<8, 2>(ntw, L.wide);
     return nullptr;
+#endif
 }
 
 }  // namespace
@@ -694,19 +820,20 @@ int tf_shade_backward(const TfShade* shade, const float* rays, int ndc, const in
     if (!fn) return (int)hipErrorInvalidValue;   // head / width outside the trained configurations
     const BwdLds L = bwd_lds(*shade);
     const size_t bytes = (size_t)L.total * sizeof(float);
-    if (bytes > 160 * 1024) return (int)hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;
-    if (!grads->dv_out || !grads->wslab || !shade->w1t || !shade->w2t) return (int)hipErrorInvalidValue;
+    if (!grads->dv_out || !grads->wslab || !grads->x_saved || !grads->rgb_fwd || !shade->w1t || !shade->w2t)
+        return (int)hipErrorInvalidValue;
     TileSrc src{counters, seg_cap, 0, app_ray, app_xyz, rays, ndc};
 #ifdef TF_PHASE_TIMING
     const int n_wg = g_dbg_bwd_wgs;
 #else
     const int n_wg = 256;
 #endif
+    const int ntw = ntw_of(kpad16(shade->in_c) / 16);
     hipLaunchKernelGGL(fn, dim3(n_wg), dim3(512), bytes, (hipStream_t)stream, *shade, src, grad_rgb, *grads);
     hipLaunchKernelGGL(wslab_reduce_kernel, dim3((unsigned)(wslab_floats(*shade) / 256)), dim3(256), 0, (hipStream_t)stream, *shade,
-                       counters, n_wg, *grads);
+                       counters, n_wg, ntw, *grads);
     if (grads->direct_scatter)
         hipLaunchKernelGGL(app_direct_scatter_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, *shade, src, *grads);
     return TF_CHECK_LAUNCH();
@@ -728,11 +855,8 @@ int tf_debug_phase_cycles_bwd(unsigned long long* out16, int reset) {
 #endif
 
 /* 1 when tf_shade_backward can differentiate this head: MLP heads of width 64 / 128, app_dim <= 32, an input of at
- * most 192 columns, and a tile (V, X, H1, H2 of 64 samples) that fits the CU's 160 KB of LDS. */
-int tf_shade_backward_supported(const TfShade* shade) {
-    if (!pick_bwd(*shade)) return 0;
-    return (size_t)bwd_lds(*shade).total * sizeof(float) <= 160 * 1024;
-}
+ * most 192 columns, and a chunk (dZ1 | V, H1, H2 | dX, X of 64 samples) that fits the CU's 160 KB of LDS. */
+int tf_shade_backward_supported(const TfShade* shade) { return pick_bwd(*shade) != nullptr; }
 
 /* floats the caller must provide in TfShadeGrads.wslab (256 workgroup slabs) */
 size_t tf_shade_backward_wslab_floats(const TfShade* shade) { return 256 * wslab_floats(*shade); }

@@ -1,6 +1,7 @@
 // tf_shade.h — pieces shared by the shading forward (shade.hip) and backward (shade_bwd.hip) kernels.
 #pragma once
 #include "tf_device.h"
+#include "tf_sincos.h"
 
 namespace tf {
 
@@ -34,26 +35,54 @@ __host__ __device__ inline ShadeLds shade_lds(const TfShade& S) {
 // tiles s_base+16b (b<NS).  W: global, row stride ldw (multiple of 16, zero padded); X: LDS, stride ldx.
 // Lane (r = lane&15, kq = lane>>4) loads W[f][16kg+4kq..+3] and X[s][16kg+4kq..+3]; MFMA step e uses
 // element e of both, i.e. k = 16kg+4kq+e on both operands.  D: row(feature) = 4*(lane>>4)+reg, col(sample) = lane&15.
+// Software-pipelined in registers: the weight fragments (L2 latency, 4 VGPRs per tile) are fetched TWO k-groups
+// ahead and the LDS fragments ONE ahead, so the 4*NF*NS MFMAs of a k-group issue while the next operands are in
+// flight (an un-pipelined loop waits out the whole L2 round trip in front of every k-group: 59 % of the MFMA rate
+// at two waves per SIMD in round 1).
 template <int NF, int NS>
 __device__ __forceinline__ void mma_block(const float* __restrict__ Wg, int ldw, int f_base, const float* Xs, int ldx,
                                           int s_base, int kgroups, f32x4 (&acc)[NF][NS], int lane) {
     const int r = lane & 15, kq = lane >> 4;
     const float* wp = Wg + (size_t)(f_base + r) * ldw + 4 * kq;
     const float* xp = Xs + (s_base + r) * ldx + 4 * kq;
-#pragma unroll 2
+    f32x4 a0[NF], a1[NF], b0[NS];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) a0[i] = *reinterpret_cast<const f32x4*>(wp + (size_t)16 * i * ldw);
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+        a1[i] = kgroups > 1 ? *reinterpret_cast<const f32x4*>(wp + (size_t)16 * i * ldw + 16) : a0[i];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) b0[j] = *reinterpret_cast<const f32x4*>(xp + 16 * j * ldx);
+#pragma unroll 1
     for (int kg = 0; kg < kgroups; ++kg) {
-        f32x4 a[NF], b[NS];
+        f32x4 a2[NF], b1[NS];
+        const int kga = kg + 2 < kgroups ? kg + 2 : kg, kgb = kg + 1 < kgroups ? kg + 1 : kg;   // tail: harmless re-reads
 #pragma unroll
-        for (int i = 0; i < NF; ++i) a[i] = *reinterpret_cast<const f32x4*>(wp + (size_t)16 * i * ldw + 16 * kg);
+        for (int i = 0; i < NF; ++i) a2[i] = *reinterpret_cast<const f32x4*>(wp + (size_t)16 * i * ldw + 16 * kga);
+#ifdef TF_B_SINGLE
 #pragma unroll
-        for (int j = 0; j < NS; ++j) b[j] = *reinterpret_cast<const f32x4*>(xp + 16 * j * ldx + 16 * kg);
+        for (int j = 0; j < NS; ++j) b0[j] = *reinterpret_cast<const f32x4*>(xp + 16 * j * ldx + 16 * kg);
+        (void)kgb;
+#else
+#pragma unroll
+        for (int j = 0; j < NS; ++j) b1[j] = *reinterpret_cast<const f32x4*>(xp + 16 * j * ldx + 16 * kgb);
+#endif
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int i = 0; i < NF; ++i)
 #pragma unroll
                 for (int j = 0; j < NS; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][e], b0[j][e], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            a0[i] = a1[i];
+            a1[i] = a2[i];
+        }
+#ifndef TF_B_SINGLE
+#pragma unroll
+        for (int j = 0; j < NS; ++j) b0[j] = b1[j];
+#endif
     }
 }
 
@@ -116,46 +145,6 @@ __device__ __forceinline__ void app_products(const TfShade& S, const float u[3],
             }
         }
     }
-}
-
-// sin and cos of the positional-encoding arguments (mlp.py:8-13).  Cody-Waite reduction by pi/2 in three
-// parts + the Cephes single-precision minimax polynomials: <= ~1.5 ulp for |x| < 8192 at ~30 VALU
-// instructions for the pair (the library sincosf carries a Payne-Hanek path and costs several times that;
-// it is still used for the rare huge argument).
-__device__ __forceinline__ void pe_sincos(float x, float* sn, float* cs) {
-    if (!(fabsf(x) < 8192.f)) {
-        sincosf(x, sn, cs);
-        return;
-    }
-    const float n = rintf(x * 0.63661977236758134f);
-    float r = fmaf(-n, 1.5703125f, x);
-    r = fmaf(-n, 4.837512969970703125e-4f, r);
-    r = fmaf(-n, 7.54978995489188e-8f, r);
-    const float r2 = r * r;
-    const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f), r2 * r, r);
-    const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f),
-                          r2 * r2, fmaf(-0.5f, r2, 1.f));
-    const int q = (int)n & 3;
-    const float s0 = (q & 1) ? pc : ps, c0 = (q & 1) ? ps : pc;
-    *sn = (q & 2) ? -s0 : s0;
-    *cs = ((q + 1) & 2) ? -c0 : c0;
-}
-
-// The Cody-Waite + polynomial part of pe_sincos alone (|x| < 8192), branch-free: lets the compiler interleave
-// several independent evaluations (the per-lane range check of pe_sincos splits the code into basic blocks).
-__device__ __forceinline__ void pe_sincos_fast(float x, float* sn, float* cs) {
-    const float n = rintf(x * 0.63661977236758134f);
-    float r = fmaf(-n, 1.5703125f, x);
-    r = fmaf(-n, 4.837512969970703125e-4f, r);
-    r = fmaf(-n, 7.54978995489188e-8f, r);
-    const float r2 = r * r;
-    const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f), r2 * r, r);
-    const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f),
-                          r2 * r2, fmaf(-0.5f, r2, 1.f));
-    const int q = (int)n & 3;
-    const float s0 = (q & 1) ? pc : ps, c0 = (q & 1) ? ps : pc;
-    *sn = (q & 2) ? -s0 : s0;
-    *cs = ((q + 1) & 2) ? -c0 : c0;
 }
 
 // One positional-encoding block of a 64-sample tile written into X (mlp.py:8-13): for every (sample, dim) the F
@@ -225,6 +214,12 @@ __device__ __forceinline__ void pe_block(float* X, int sx, int off, int D, int F
             }
         }
     }
+}
+
+// row / quad of item q of a [64][w4] quad image without an integer division (q < 4096, w4 <= 96: exact)
+__device__ __forceinline__ void row_quad(int q, int w4, float inv_w4, int& row, int& c4) {
+    row = (int)(((float)q + 0.5f) * inv_w4);
+    c4 = q - row * w4;
 }
 
 // real SH basis, degree 2 (sh.py:87-112)

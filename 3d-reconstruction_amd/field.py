@@ -171,8 +171,11 @@ class _Workspace:
         if save_valid:
             spec += [("val_idx", R * N, torch.int32), ("val_feat", R * N, torch.float32),
                      ("grad_rgb", cap * 3, torch.float32), ("rgb_pre", R * 3, torch.float32)]
-            n_app, wslab = train_extra
-            spec += [("dv", cap * n_app, torch.float32), ("wslab", wslab, torch.float32)]
+            n_app, wslab, kp_in = train_extra
+            # dv: plane*line product rows saved by the forward, replaced by dL/dV rows in the backward; xs: the MLP
+            # input rows saved by the forward (TfShadeSave)
+            spec += [("dv", cap * n_app, torch.float32), ("wslab", wslab, torch.float32),
+                     ("xs", cap * kp_in, torch.float32)]
             if binned is not None:   # binned gradient scatter (csrc/bin.hip): entry lists + sort workspace
                 nkeys, kpe = max(binned[0], binned[1]), binned[2]
                 n_ints = 4 * (nkeys + 8) + kpe * cap // 256 + 64
@@ -584,7 +587,7 @@ class TensorBase(nn.Module):
                         f"app_dim={self.app_dim} (<= 32), MLP input {sh.in_c} (<= 192), sum(app_n_comp)="
                         f"{self._n_app_total()} (<= 384, and the 64-sample tile must fit the 160 KB of LDS)")
                 wslab = int(H.lib().tf_shade_backward_wslab_floats(C.byref(sh))) if sh.head == H.HEAD_MLP else 64
-                extra = (self._n_app_total(), wslab)
+                extra = (self._n_app_total(), wslab, (int(sh.in_c) + 15) // 16 * 16 if sh.head == H.HEAD_MLP else 0)
             ws = _Workspace(R, N, dev, save_valid, self._debug_masks, binned, extra)
             if not save_valid:
                 self._ws_cache = {key: ws}
@@ -668,9 +671,14 @@ class TensorBase(nn.Module):
             io.dbg_app_bits = ws.dbg_app.data_ptr()
         self._timed("tf_march_forward", lib.tf_march_forward, C.byref(field), C.byref(io), st)
         sorted_on = after_march(ws, field, shade) if early else None
+        save = None
+        if save_valid and shade.head == H.HEAD_MLP:      # rows the backward streams back instead of recomputing them
+            save = H.TfShadeSave()
+            save.x, save.v = ws.xs.data_ptr(), ws.dv.data_ptr()
         self._timed("tf_shade_forward", lib.tf_shade_forward, C.byref(shade), rays.data_ptr(), int(bool(ndc_ray)),
                     ws.counters.data_ptr(), ws.seg_cap, ws.app_ray.data_ptr(), ws.app_xyz.data_ptr(),
-                    ws.rgb.data_ptr(), self.shade_wgs_beside_sort if sorted_on is not None else 0, st)
+                    ws.rgb.data_ptr(), self.shade_wgs_beside_sort if sorted_on is not None else 0,
+                    C.byref(save) if save is not None else None, st)
         self._timed("tf_composite_forward", lib.tf_composite_forward, R, ws.app_offset.data_ptr(),
                     ws.app_count.data_ptr(), ws.app_w.data_ptr(), ws.rgb.data_ptr(), ws.acc.data_ptr(), int(use_bg),
                     out_rgb.data_ptr(), ws.rgb_pre.data_ptr() if save_valid else None, ws.counters.data_ptr(),

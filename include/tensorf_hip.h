@@ -191,8 +191,13 @@ int tf_march_forward(const TfField* field, const TfMarchIO* io, tf_stream_t stre
  * tensorBase.py:343); rgb_out is (capacity,3), written at the packed positions.  The kernel is persistent (tiles
  * are handed out by a ticket): max_workgroups (0 = all 512 slots, two per CU) leaves CU slots free for kernels the
  * caller runs next to it on another stream (the training step's early sorts of the binned scatter). */
+typedef struct TfShadeSave {  /* training: rows kept for tf_shade_backward (both NULL in inference) */
+    float* x;              /* (cap, kpad(in_c)): MLP input [feat, view, PE blocks] of every packed sample, zero padded */
+    float* v;              /* (cap, n_app_total): plane*line products (the operand of basis_mat, tensoRF.py:263) */
+} TfShadeSave;
 int tf_shade_forward(const TfShade* shade, const float* rays, int ndc, const int* counters, int seg_cap,
-                     const int* app_ray, const float* app_xyz, float* rgb_out, int max_workgroups, tf_stream_t stream);
+                     const int* app_ray, const float* app_xyz, float* rgb_out, int max_workgroups,
+                     const TfShadeSave* save, tf_stream_t stream);
 
 /* rgb_map = sum w*rgb (+ 1-acc when bg) clamped to [0,1]: tensorBase.py:378-384.  rgb_pre (optional)
  * receives the pre-clamp value, which the backward needs for the clamp mask.  n_shaded (optional, with the sharded
@@ -216,17 +221,21 @@ int tf_march_backward(const TfField* field, const TfMarchIO* io, const float* gr
  * density sample with a non-zero gradient to the sharded entry list (counter slot 3) for tf_binned_scatter.
  * When io->ent_offset is set the forward has already placed the entries (TfMarchIO.ent_xyz): only ent_df is written. */
 
-/* Backward of the shading head + appearance lookup: recomputes the tile forward, then accumulates
- * gradients of w1,b1,w2,b2,w3,b3, basis and the appearance factors.  Gradient matrices use the
- * reference's own (unpadded, row-major) layouts. */
+/* Backward of the shading head + appearance lookup (autograd of tensoRF.py:230-263, mlp.py:27-155): re-runs the two
+ * hidden layers of each 64-sample chunk on the rows the training forward saved (TfShadeSave: MLP inputs and
+ * plane*line products; the colours are the forward's rgb_out), then accumulates gradients of w1,b1,w2,b2,w3,b3,
+ * basis and the appearance factors.  Gradient matrices use the reference's own (unpadded, row-major) layouts. */
 typedef struct TfShadeGrads {
     float* w1; float* b1; float* w2; float* b2; float* w3; float* b3;
     float* basis;          /* (app_dim, n_app_total) */
     TfFactorGrads app;
-    float* dv_out;         /* (cap, n_app_total): dL/dV rows of the packed samples, consumed by the scatter stage */
+    float* dv_out;         /* (cap, n_app_total): on entry the V rows saved by the forward (TfShadeSave.v), on exit
+                            * the dL/dV rows of the packed samples, consumed by the scatter stage */
     float* wslab;          /* tf_shade_backward_wslab_floats() floats: per-workgroup weight-gradient slabs */
     int direct_scatter;    /* 1: scatter dv_out with per-tap atomics inside the call (TensorCP / binning disabled);
                             * 0: the caller runs tf_binned_scatter on dv_out */
+    const float* x_saved;  /* (cap, kpad(in_c)): MLP input rows saved by the forward (TfShadeSave.x) */
+    const float* rgb_fwd;  /* (cap, 3): the forward's rgb_out (sigmoid outputs) */
 } TfShadeGrads;
 size_t tf_shade_backward_wslab_floats(const TfShade* shade);
 /* 1 when tf_shade_backward supports this head (MLP, feature_c 64 / 128, app_dim <= 32, in_c <= 192, and the

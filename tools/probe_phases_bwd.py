@@ -29,9 +29,9 @@ for rep in range(2):
         loss.backward()
     torch.cuda.synchronize()
     lib.tf_debug_phase_cycles_bwd(out, 1)
-names = ["info+out layer", "dW3/dZ2 pass", "dW2", "dH1->dZ1", "db1+dW1", "featcopy+dX", "dfeat+dB+dV", "dV store",
-         "gather", "basis", "PE", "layer1", "layer2"]
-tot = sum(out[i] for i in range(13))
+names = ["P1 X,dO->LDS", "P2 layer1", "P3 layer2+dZ2", "P4a dH1->dZ1", "P4b dW2", "P5a dW1", "P5b dX", "P6 dfeat,V->LDS",
+         "P7a dB", "P7b dV"]
+tot = sum(out[i] for i in range(len(names)))
 ntile = sum((int(c) + 63) // 64 for c in model.last["ws"].counters2d[:, 0].tolist())
 print("tiles in last batch", ntile)
 for i, n in enumerate(names):
