@@ -120,7 +120,7 @@ __host__ __device__ inline BwdLds bwd_lds(const TfShade& S) {
     L.sh = S.feature_c + 4;
     L.sf = 36;                       // dfeat rows (<= 32 used)
     const int hreg = M * (2 * L.sh > L.sx ? 2 * L.sh : L.sx);      // H1 | H2, later dX
-    const int consts = 5 * S.feature_c + 8;                         // w3 (3 F), b1, b2, reduction scratch
+    const int consts = 10 * S.feature_c + 8;                        // w3 (3 F), b1, b2; sums of dW3 (3 F), db2, db1; scratch
     for (L.wide = 0; L.wide < 2; ++L.wide) {
         const int vreg = M * (L.wide || L.sh > L.sv ? L.sh : L.sv);   // dZ1, later V (narrow)
         L.offV = 0;
@@ -248,7 +248,10 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
     float* cw3 = lds + L.offC;            // [3][FC]
     float* cb1 = cw3 + 3 * FCc;
     float* cb2 = cb1 + FCc;
-    float* cred = cb2 + FCc;              // [8] reduction scratch
+    float* sW3 = cb2 + FCc;               // [3][FC] dW3, [FC] db2, [FC] db1: this workgroup's sums over its chunks
+    float* sb2 = sW3 + 3 * FCc;
+    float* sb1 = sb2 + FCc;
+    float* cred = sb1 + FCc;              // [8] reduction scratch
     int* pre = reinterpret_cast<int*>(lds + L.offPre);
     const int tid0 = threadIdx.x;
     const int kp1 = kpad16(S.in_c), kt1 = kp1 / 16, kpB = kpad16(S.n_app_total), ktB = kpB / 16;
@@ -268,12 +271,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
     zero_acc(aW1);
     f32x4 aB[KTBW][NB];
     zero_acc(aB);
-    float aW3[3][4], ab2[4], ab1[4], ab3 = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        aW3[0][e] = aW3[1][e] = aW3[2][e] = 0.f;
-        ab2[e] = ab1[e] = 0.f;
-    }
+    float ab3 = 0.f;
 
     if (tid0 == 0) {
         int run = 0;
@@ -284,6 +282,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         pre[TF_N_SHARDS] = run;
     }
     for (int i = tid0; i < 3 * FCc; i += NT) cw3[i] = S.w3[i];
+    for (int i = tid0; i < 5 * FCc; i += NT) sW3[i] = 0.f;
     if (tid0 < FCc) {
         cb1[tid0] = S.b1[tid0];
         cb2[tid0] = S.b2[tid0];
@@ -344,14 +343,23 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
             ab3 += d;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of X are in LDS
+        f32x4 fr1[2 * NTW][1];                                // weight fragments of P2, in flight across the barrier
+#ifndef TF_X_LATE1
+        load_a_frags<1, 2 * NTW>(S.w1, kp1, 16 * my_ft, kt1, lane, fr1);
+#endif
         lds_barrier();
         TF_MARK(0);
+#ifdef TF_X_LATE1
+        load_a_frags<1, 2 * NTW>(S.w1, kp1, 16 * my_ft, kt1, lane, fr1);
+#endif
 
         // ================= P2: layer 1 -> H1 =================
+        f32x4 fr2[FT][1];
         {
             f32x4 acc[1][NSW];
             zero_acc(acc);
-            mma_block<1, NSW>(S.w1, kp1, 16 * my_ft, X, L.sx, s_base, kt1, acc, lane);
+            mma_frags<1, NSW, 2 * NTW>(fr1, X, L.sx, s_base, kt1, acc, lane);
+            load_a_frags<1, FT>(S.w2, FCc, 16 * my_ft, FT, lane, fr2);      // P3's weights: behind this epilogue + barrier
             const int f = 16 * my_ft + 4 * lg;
             const f32x4 bias = *reinterpret_cast<const f32x4*>(cb1 + f);
 #pragma unroll
@@ -366,15 +374,20 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         TF_MARK(1);
 
         // ================= P3: layer 2 -> H2; dW3, dZ2 (in place of H2), db2 in the epilogue =================
+        f32x4 fr3[FT][1];
         {
             f32x4 acc[1][NSW];
             zero_acc(acc);
-            mma_block<1, NSW>(S.w2, FCc, 16 * my_ft, H1, L.sh, s_base, FCc / 16, acc, lane);
+            mma_frags<1, NSW, FT>(fr2, H1, L.sh, s_base, FT, acc, lane);
+            load_a_frags<1, FT>(S.w2t, FCc, 16 * my_ft, FT, lane, fr3);     // P4's weights
             const int f = 16 * my_ft + 4 * lg;
             const f32x4 bias = *reinterpret_cast<const f32x4*>(cb2 + f);
             const f32x4 w0 = *reinterpret_cast<const f32x4*>(cw3 + f);
             const f32x4 w1 = *reinterpret_cast<const f32x4*>(cw3 + FCc + f);
             const f32x4 w2 = *reinterpret_cast<const f32x4*>(cw3 + 2 * FCc + f);
+            float aW3[3][4], ab2[4];          // this chunk's, this lane's samples
+#pragma unroll
+            for (int e = 0; e < 4; ++e) aW3[0][e] = aW3[1][e] = aW3[2][e] = ab2[e] = 0.f;
 #pragma unroll
             for (int j = 0; j < NSW; ++j) {
                 const int s = s_base + 16 * j + lc;
@@ -391,16 +404,32 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                 }
                 *reinterpret_cast<f32x4*>(H2 + s * L.sh + f) = dz;
             }
+            // sums over the 16 sample lanes (DPP), then one LDS add per feature: the per-feature vectors would cost
+            // 20 registers per lane if they stayed in registers across the chunks
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v0 = row16_sum(aW3[0][e]), v1 = row16_sum(aW3[1][e]), v2 = row16_sum(aW3[2][e]);
+                const float v3 = row16_sum(ab2[e]);
+                if (lc == 0) {
+                    atomicAdd(sW3 + f + e, v0);
+                    atomicAdd(sW3 + FCc + f + e, v1);
+                    atomicAdd(sW3 + 2 * FCc + f + e, v2);
+                    atomicAdd(sb2 + f + e, v3);
+                }
+            }
         }
         lds_barrier();
         TF_MARK(2);
 
         // ================= P4: dZ1 = (W2^T dZ2) . [H1 > 0] -> DZ1, db1;  dW2 += dZ2^T H1 =================
+        f32x4 frx[1][FT][1];       // dX (P5): weight fragments of the wave's current work item
         {
             f32x4 acc[1][NSW];
             zero_acc(acc);
-            mma_block<1, NSW>(S.w2t, FCc, 16 * my_ft, H2, L.sh, s_base, FCc / 16, acc, lane);
+            mma_frags<1, NSW, FT>(fr3, H2, L.sh, s_base, FT, acc, lane);
+            if (wave < 2 * kt1) load_a_frags<1, FT>(S.w1t, FCc, 16 * (wave >> 1), FT, lane, frx[0]);
             const int f = 16 * my_ft + 4 * lg;
+            float ab1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < NSW; ++j) {
                 const int s = s_base + 16 * j + lc;
@@ -412,6 +441,11 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                     ab1[e] += dz[e];
                 }
                 *reinterpret_cast<f32x4*>(DZ1 + s * L.sh + f) = dz;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v4 = row16_sum(ab1[e]);
+                if (lc == 0) atomicAdd(sb1 + f + e, v4);
             }
             TF_MARK(3);
             // dW2[f2][f1]: wave -> (f2 block of FC/2, f1 block of FC/4)
@@ -449,14 +483,19 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         TF_MARK(5);
         // dX[k][s] = sum_f W1[f][k] dZ1[s][f].  Work items are (k tile, pair of sample tiles): 2 kt1 items dealt
         // round-robin (waves w and w + 4 share a SIMD, so 2.5 items per wave are 5 per SIMD)
-        for (int it = wave; it < 2 * kt1; it += NW) {
-            const int kt = it >> 1, sp = it & 1;
-            f32x4 acc[1][2];
-            zero_acc(acc);
-            mma_block<1, 2>(S.w1t, FCc, 16 * kt, DZ1, L.sh, 32 * sp, FCc / 16, acc, lane);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                *reinterpret_cast<f32x4*>(DX + (32 * sp + 16 * j + lc) * L.sx + 16 * kt + 4 * lg) = acc[0][j];
+        for (int round = 0; round < 3; ++round) {       // 2 kt1 <= 24 items over 8 waves
+            const int it = wave + NW * round;
+            if (it < 2 * kt1) {
+                const int kt = it >> 1, sp = it & 1;
+                if (round > 0) load_a_frags<1, FT>(S.w1t, FCc, 16 * kt, FT, lane, frx[0]);
+                f32x4 acc[1][2];
+                zero_acc(acc);
+                mma_frags<1, 2, FT>(frx[0], DZ1, L.sh, 32 * sp, FT, acc, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    *reinterpret_cast<f32x4*>(DX + (32 * sp + 16 * j + lc) * L.sx + 16 * kt + 4 * lg) = acc[0][j];
+            }
         }
         lds_barrier();
         TF_MARK(6);
@@ -511,6 +550,23 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                 for (int c = lane; c < nat; c += 64) V[smp * L.sv + c] = smp < n ? dv[ck.at(smp) * nat + c] : 0.f;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of V are in LDS
+        // basis fragments of the wave's first dV unit (P7), in flight across the barrier
+        const int g4 = ktB >> 2, n_units = 4 * (g4 + (ktB & 3));
+        f32x4 bfr[4 * NB];
+        {
+            const int u0 = NW - 1 - wave, r = lane & 15, kq = lane >> 4;
+            const bool full = (u0 >> 2) < g4;
+            const float* np = S.basis + (size_t)kq * kpB + (full ? 64 * (u0 >> 2) + 4 * r : 64 * g4 + 16 * ((u0 >> 2) - g4) + r);
+#pragma unroll
+            for (int t = 0; t < 4 * NB; ++t) {
+                bfr[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (u0 < n_units) {
+                    if (full) bfr[t] = *reinterpret_cast<const f32x4*>(np + (size_t)4 * t * kpB);
+                    else bfr[t][0] = np[(size_t)4 * t * kpB];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         lds_barrier();
         if (WIDE) {     // the V tile needs the dZ1 | H space, which dfeat has just finished reading
             for (int smp = wave; smp < M; smp += NW)
@@ -526,51 +582,34 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
             else n_g = n_c = 0.f;
         }
 
-        // ================= P7: dB += dfeat^T V;  dV = B^T dfeat -> dv_out =================
-#ifndef TF_X_NODB
-        {   // dB[f][c]: A = Fd (NB elements per lane: f = NB i + e), B = V column tiles wave, wave + 8, wave + 16
-            const int r = lane & 15, kq = lane >> 4;
-            const float* ap = Fd + kq * L.sf + NB * r;
-            const float* bp = V + kq * L.sv + 16 * wave + r;
-#pragma unroll 2
-            for (int t = 0; t < M / 4; ++t) {
-                float a[NB];
-                ldv<NB>(ap + 4 * t * L.sf, a);
-#pragma unroll
-                for (int k = 0; k < KTBW; ++k) {
-                    if (wave + NW * k < ktB) {
-                        const float b = bp[4 * t * L.sv + 128 * k];
-#pragma unroll
-                        for (int e = 0; e < NB; ++e)
-                            aB[k][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b, aB[k][e], 0, 0, 0);
-                    }
-                }
-            }
-        }
-#endif
-        TF_MARK(8);
-#ifndef TF_X_NODV
+        // ================= P7: dV = B^T dfeat -> dv_out;  dB += dfeat^T V =================
         {   // dV[s][c] = sum_f B[f][c] dfeat[s][f]: units (group of 4 column tiles | single tile, sample tile), dealt from
             // the last wave down (the low waves own the extra dB tiles).  A = packed basis rows f (k index), read
-            // 4 columns per lane; B = Fd[s][f].  The accumulators go straight to dv_out.
+            // 4 columns per lane (its fragments `bfr` were requested before P6's barrier; the next unit's replace them
+            // k-step by k-step behind the MFMAs that consumed them); B = Fd[s][f].  The accumulators go straight to
+            // dv_out, ahead of the dB loop, so that the stores have retired when the next chunk waits for its X rows.
             const int r = lane & 15, kq = lane >> 4;
-            const int g4 = ktB >> 2, n_units = 4 * (g4 + (ktB & 3));
             for (int u = NW - 1 - wave; u < n_units; u += NW) {
-                const int st = u & 3, grp = u >> 2;
+                const int st = u & 3, grp = u >> 2, un = u + NW;
                 const float* bp = Fd + (16 * st + r) * L.sf + kq;
                 const int s = 16 * st + lc;
+                const bool nxt = un < n_units, nxt_full = (un >> 2) < g4;
+                const float* np = S.basis + (size_t)kq * kpB + (nxt_full ? 64 * (un >> 2) + 4 * r : 64 * g4 + 16 * ((un >> 2) - g4) + r);
                 if (grp < g4) {
                     const int cb = 64 * grp;
                     f32x4 acc[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    const float* ap = S.basis + (size_t)kq * kpB + cb + 4 * r;
 #pragma unroll
                     for (int t = 0; t < 4 * NB; ++t) {
-                        const f32x4 a = *reinterpret_cast<const f32x4*>(ap + (size_t)4 * t * kpB);
+                        const f32x4 a = bfr[t];
                         const float b = bp[4 * t];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b, acc[e], 0, 0, 0);
+                        if (nxt) {
+                            if (nxt_full) bfr[t] = *reinterpret_cast<const f32x4*>(np + (size_t)4 * t * kpB);
+                            else bfr[t][0] = np[(size_t)4 * t * kpB];
+                        }
                     }
                     if (s < n) {     // element (e, reg): column cb + 4 (4 lg + reg) + e
                         float* o = dv + ck.at(s) * nat;
@@ -589,10 +628,14 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                 } else {
                     const int cb = 64 * g4 + 16 * (grp - g4);
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    const float* ap = S.basis + (size_t)kq * kpB + cb + r;
 #pragma unroll
-                    for (int t = 0; t < 4 * NB; ++t)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(size_t)4 * t * kpB], bp[4 * t], acc, 0, 0, 0);
+                    for (int t = 0; t < 4 * NB; ++t) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[t][0], bp[4 * t], acc, 0, 0, 0);
+                        if (nxt) {
+                            if (nxt_full) bfr[t] = *reinterpret_cast<const f32x4*>(np + (size_t)4 * t * kpB);
+                            else bfr[t][0] = np[(size_t)4 * t * kpB];
+                        }
+                    }
                     if (s < n) {     // element reg: column cb + 4 lg + reg
                         float* o = dv + ck.at(s) * nat;
                         const int c = cb + 4 * lg;
@@ -607,7 +650,37 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                 }
             }
         }
-#endif
+        TF_MARK(8);
+        {   // dB[f][c]: A = Fd (NB elements per lane: f = NB i + e), B = V column tiles wave, wave + 8, wave + 16;
+            // both from LDS, fetched one k-step ahead
+            const int r = lane & 15, kq = lane >> 4;
+            const float* ap = Fd + kq * L.sf + NB * r;
+            const float* bp = V + kq * L.sv + 16 * wave + r;
+            float a[NB], b[KTBW];
+            ldv<NB>(ap, a);
+#pragma unroll
+            for (int k = 0; k < KTBW; ++k) b[k] = wave + NW * k < ktB ? bp[128 * k] : 0.f;
+#pragma unroll
+            for (int t = 0; t < M / 4; ++t) {
+                float an[NB], bn[KTBW];
+                const int tn = t + 1 < M / 4 ? t + 1 : t;
+                ldv<NB>(ap + 4 * tn * L.sf, an);
+#pragma unroll
+                for (int k = 0; k < KTBW; ++k) bn[k] = wave + NW * k < ktB ? bp[4 * tn * L.sv + 128 * k] : 0.f;
+#pragma unroll
+                for (int k = 0; k < KTBW; ++k) {
+                    if (wave + NW * k < ktB) {
+#pragma unroll
+                        for (int e = 0; e < NB; ++e)
+                            aB[k][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[k], aB[k][e], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < NB; ++e) a[e] = an[e];
+#pragma unroll
+                for (int k = 0; k < KTBW; ++k) b[k] = bn[k];
+            }
+        }
         first = false;
         TF_MARK(9);
         // no barrier here: the next chunk's P1 writes X and dO only, which nothing in P7 reads (a WIDE V tile lies over X)
@@ -647,28 +720,13 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
             }
         }
     }
-    // ================= the per-feature vectors: reduce over the 16 sample lanes, then one atomic per feature ===========
+    // ================= the per-feature vectors (summed in LDS over this workgroup's chunks): one atomic per entry ======
     {
-        const int wave = tid3 >> 6, lane = tid3 & 63, lc = lane & 15, lg = lane >> 4;
-        const int f = 16 * (wave % FT) + 4 * lg;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v0 = aW3[0][e], v1 = aW3[1][e], v2 = aW3[2][e], v3 = ab2[e], v4 = ab1[e];
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                v0 += __shfl_xor(v0, o, 64);
-                v1 += __shfl_xor(v1, o, 64);
-                v2 += __shfl_xor(v2, o, 64);
-                v3 += __shfl_xor(v3, o, 64);
-                v4 += __shfl_xor(v4, o, 64);
-            }
-            if (lc == 0) {
-                atomicAdd(G.w3 + f + e, v0);
-                atomicAdd(G.w3 + FCc + f + e, v1);
-                atomicAdd(G.w3 + 2 * FCc + f + e, v2);
-                atomicAdd(G.b2 + f + e, v3);
-                atomicAdd(G.b1 + f + e, v4);
-            }
+        __syncthreads();
+        for (int i = tid3; i < 3 * FCc; i += NT) atomicAdd(G.w3 + i, sW3[i]);
+        if (tid3 < FCc) {
+            atomicAdd(G.b2 + tid3, sb2[tid3]);
+            atomicAdd(G.b1 + tid3, sb1[tid3]);
         }
         // db3: thread (sample, channel) sums over its chunks -> LDS -> one atomic per channel
         __syncthreads();

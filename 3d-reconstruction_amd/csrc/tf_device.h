@@ -59,6 +59,13 @@ __device__ __forceinline__ float quad_sum(float v) {
     v += quad_xor2(v);
     return v;
 }
+// sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15), result in every lane of the row; VALU only (DPP)
+__device__ __forceinline__ float row16_sum(float v) {
+    v = quad_sum(v);
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x124, 0xF, 0xF, true));   // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xF, 0xF, true));   // row_ror:8
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

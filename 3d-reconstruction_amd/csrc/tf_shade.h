@@ -86,6 +86,60 @@ __device__ __forceinline__ void mma_block(const float* __restrict__ Wg, int ldw,
     }
 }
 
+// ---- the same GEMM with the weight fragments of the WHOLE phase fetched up front -------------------------------
+// A phase is a handful of k-groups (<= 12): all of its weight fragments fit in registers (4 VGPRs per k-group and
+// feature tile), so they are requested one phase early — before the barrier in front of the phase, behind the previous
+// phase's epilogue — and the MFMA loop itself touches LDS only.  (A loop that fetches its weights as it goes leaves the
+// L2 round trip in front of the first k-groups of every phase; the compiler also answers register rotation with
+// s_waitcnt vmcnt(0) right behind each fetch.)
+template <int NF, int KG>
+__device__ __forceinline__ void load_a_frags(const float* __restrict__ Wg, int ldw, int f_base, int kgroups, int lane,
+                                             f32x4 (&a)[KG][NF]) {
+    const int r = lane & 15, kq = lane >> 4;
+    const float* wp = Wg + (size_t)(f_base + r) * ldw + 4 * kq;
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+            a[kg][i] = kg < kgroups ? *reinterpret_cast<const f32x4*>(wp + (size_t)16 * i * ldw + 16 * kg) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    // keep the requests HERE: without the fence the scheduler sinks each load down to its first use and waits for it
+    // there (s_waitcnt vmcnt(0) per fragment: eight serialized L2 round trips per phase)
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int NF, int NS, int KG>
+__device__ __forceinline__ void mma_frags(const f32x4 (&a)[KG][NF], const float* Xs, int ldx, int s_base, int kgroups,
+                                          f32x4 (&acc)[NF][NS], int lane) {
+    // The LDS fragments are consumed in steps of PW sample tiles (PW = 2: two accumulator chains alternate, 64 cycles
+    // between dependent MFMAs >= the 40-cycle latency) and fetched one step ahead: 2 x PW fragments live instead of
+    // 2 x NS for a whole k-group.
+    constexpr int PW = NS >= 2 ? 2 : 1, NP = NS / PW, STEPS = KG * NP;
+    static_assert(NS % PW == 0, "sample tiles come in pairs");
+    const int r = lane & 15, kq = lane >> 4;
+    const float* xp = Xs + (s_base + r) * ldx + 4 * kq;
+    f32x4 b[2][PW];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) b[0][j] = *reinterpret_cast<const f32x4*>(xp + 16 * j * ldx);
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+        const int kg = st / NP, pr = st % NP;
+        if (kg < kgroups) {
+            const int kg1 = (st + 1) / NP, pr1 = (st + 1) % NP;
+            if (st + 1 < STEPS && kg1 < kgroups) {
+#pragma unroll
+                for (int j = 0; j < PW; ++j)
+                    b[(st + 1) & 1][j] = *reinterpret_cast<const f32x4*>(xp + 16 * (PW * pr1 + j) * ldx + 16 * kg1);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < NF; ++i)
+#pragma unroll
+                    for (int j = 0; j < PW; ++j)
+                        acc[i][PW * pr + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kg][i][e], b[st & 1][j][e], acc[i][PW * pr + j], 0, 0, 0);
+        }
+    }
+}
+
 // Products (P*m)(L*m) [VM] or (L0*L1*L2)*m [CP] of one sample, channel quads sub, sub+4, ..., written to
 // vrow[0 .. n_app_total).
 // `lps` lanes cooperate on one sample (lane `sub` takes channel quads sub, sub+lps, ...)
