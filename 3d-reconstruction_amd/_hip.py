@@ -7,8 +7,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtensorf_hip_diag.so" if os.environ.get("TF_DIAG") == "1"
-                        else "libtensorf_hip.so")
+# TF_DIAG=1 loads the instrumented build (phase timers; tools/probe_phases*.py), TF_DIAG=<name> the experiment build
+# lib/libtensorf_hip_<name>.so (tools only; never used for reported numbers)
+_diag = os.environ.get("TF_DIAG", "")
+LIB_PATH = os.path.join(_HERE, "lib", "libtensorf_hip.so" if not _diag else
+                        ("libtensorf_hip_diag.so" if _diag == "1" else f"libtensorf_hip_{_diag}.so"))
 
 N_SHARDS = 64
 SHARD_STRIDE = 32
@@ -65,11 +68,11 @@ class TfShade(C.Structure):
 class TfShadeGrads(C.Structure):
     _fields_ = [("w1", _fp), ("b1", _fp), ("w2", _fp), ("b2", _fp), ("w3", _fp), ("b3", _fp),
                 ("basis", _fp), ("app", TfFactorGrads), ("dv_out", _fp), ("wslab", _fp), ("direct_scatter", C.c_int),
-                ("x_saved", _fp), ("rgb_fwd", _fp)]
+                ("x_saved", _fp), ("h1_saved", _fp), ("h2_saved", _fp), ("rgb_fwd", _fp)]
 
 
 class TfShadeSave(C.Structure):
-    _fields_ = [("x", _fp), ("v", _fp)]
+    _fields_ = [("x", _fp), ("v", _fp), ("h1", _fp), ("h2", _fp)]
 
 
 class TfBinJob(C.Structure):

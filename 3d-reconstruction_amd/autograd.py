@@ -166,6 +166,7 @@ class _RenderFn(torch.autograd.Function):
         sg.app = ag
         sg.dv_out, sg.wslab = ws.dv.data_ptr(), ws.wslab.data_ptr()
         sg.x_saved, sg.rgb_fwd = ws.xs.data_ptr(), ws.rgb.data_ptr()
+        sg.h1_saved, sg.h2_saved = ws.h1s.data_ptr(), ws.h2s.data_ptr()
         sg.direct_scatter = 0 if binned else 1
         model._timed("tf_shade_backward", lib.tf_shade_backward, C.byref(c['shade']), c['rays'].data_ptr(),
                      int(c['ndc']), ws.counters.data_ptr(), ws.seg_cap, ws.app_ray.data_ptr(), ws.app_xyz.data_ptr(),

@@ -15,6 +15,18 @@ using namespace tf;
 
 namespace {
 
+// training: copy a [n][w] row block of an LDS tile (row stride ld floats, w a multiple of 4) to global rows, 16 B per lane
+template <int NT>
+__device__ __forceinline__ void save_rows(float* dst, const float* tile, int ld, int w, int n, int tid) {
+    const int w4 = w >> 2;
+    const float inv = 1.f / (float)w4;
+    for (int q = tid; q < n * w4; q += NT) {
+        int row, c4;
+        row_quad(q, w4, inv, row, c4);
+        *reinterpret_cast<f32x4*>(dst + (size_t)q * 4) = *reinterpret_cast<const f32x4*>(tile + row * ld + 4 * c4);
+    }
+}
+
 // FT = feature_c / 16 hidden feature tiles (4, 8 or 16), NB = ceil(app_dim/16) basis feature tiles.
 // 512 threads = 8 waves shade one 64-sample tile; two workgroups share a CU (81,680 B of LDS each), i.e. 4 waves per
 // SIMD (<= 128 VGPRs).  A launch has only ~5 tiles per CU: the chain of dependent phases of one tile is spread over
@@ -234,6 +246,7 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
         }
         __syncthreads();
         TF_MARK(4);
+        if (save.h1) save_rows<NT>(save.h1 + (size_t)s0 * FC, regA, L.sh, FC, n, tid);
         {
             f32x4 acc[NFW][NSW];
 #pragma unroll
@@ -257,6 +270,7 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
         }
         __syncthreads();
         TF_MARK(5);
+        if (save.h2) save_rows<NT>(save.h2 + (size_t)s0 * FC, regB, L.sh, FC, n, tid);
 
         // ---- 5. output layer + sigmoid: 8 lanes per sample
         {
@@ -315,7 +329,7 @@ shade_fn_t pick_kernel(const TfShade& S) {
 }
 
 int launch_shade(const TfShade* S, const TileSrc& src, float* rgb_out, float* feat_out, int blocks, hipStream_t st,
-                 TfShadeSave save = TfShadeSave{nullptr, nullptr}) {
+                 TfShadeSave save = TfShadeSave{nullptr, nullptr, nullptr, nullptr}) {
     shade_fn_t fn = pick_kernel(*S);
     if (!fn) return (int)hipErrorInvalidValue;
     if (S->head == TF_HEAD_SH && S->app_dim != 27) return (int)hipErrorInvalidValue;
@@ -338,7 +352,7 @@ int tf_shade_forward(const TfShade* shade, const float* rays, int ndc, const int
     TileSrc src{counters, seg_cap, 0, app_ray, app_xyz, rays, ndc};
     const int wgs = max_workgroups > 0 && max_workgroups < 512 ? max_workgroups : 512;
     if (save && shade->head != TF_HEAD_MLP && save->x) return (int)hipErrorInvalidValue;   // X rows exist for MLP heads only
-    return launch_shade(shade, src, rgb_out, nullptr, wgs, (hipStream_t)stream, save ? *save : TfShadeSave{nullptr, nullptr});
+    return launch_shade(shade, src, rgb_out, nullptr, wgs, (hipStream_t)stream, save ? *save : TfShadeSave{nullptr, nullptr, nullptr, nullptr});
 }
 
 int tf_appfeature_points(const TfShade* shade, const float* xyz_n, int n, float* out_feat, tf_stream_t stream) {

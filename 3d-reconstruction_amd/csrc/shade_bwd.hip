@@ -3,23 +3,22 @@
 //
 // One persistent 512-thread workgroup (8 waves, 2 per SIMD) per CU walks <= 64-sample chunks of the packed app list.
 // The training forward (tf_shade_forward with TfShadeSave) has left, per packed sample, the MLP input row
-// X = [feat, view, PE blocks] and the product row V = plane*line; the sigmoid output is the forward's rgb.  So the
-// gather, the basis contraction, the positional encoding and the output layer are NOT recomputed: X and V are streamed
-// back (prefetched through registers one phase / one chunk ahead), only the two hidden layers are.  Per chunk:
-//     P1  X (registers -> LDS); do = dL/dc . c(1-c) from the forward's colours
-//     P2  H1 = relu(W1 X + b1)                                            MFMA, weights streamed from L2
-//     P3  H2 = relu(W2 H1 + b2); epilogue, per accumulator element: dW3 += do^T H2, dZ2 = (do W3) . [H2>0] (in place
-//         of H2), db2 += dZ2                                                MFMA
+// X = [feat, view, PE blocks], both hidden layers H1, H2 (after ReLU) and the product row V = plane*line; the sigmoid
+// output is the forward's rgb.  NOTHING of the forward is recomputed: the rows are streamed back by LDS-DMA
+// (global_load_lds: no registers, asynchronous), one chunk / one phase ahead.  Per chunk:
+//     P1  wait for X, H1, H2 (requested during the previous chunk's P7); do = dL/dc . c(1-c) from the forward's colours
+//     P3  elementwise on H2: dW3 += do^T H2, dZ2 = (do W3) . [H2>0] (in place of H2), db2 += dZ2
 //     P4  dZ1 = (W2^T dZ2) . [H1>0] -> its own buffer, db1 += dZ1;  dW2 += dZ2^T H1          MFMA (two GEMMs, no barrier)
-//     P5  dW1 += dZ1^T X;  dX = W1^T dZ1 -> its own buffer                                       MFMA (two GEMMs)
-//     P6  dfeat = dX[:, :D] + PE'(feat) . dX[:, PE cols];  V (registers -> LDS, over dZ1)
-//     P7  dB += dfeat^T V;  dV = B^T dfeat -> straight from the accumulators to dv_out             MFMA (two GEMMs)
-// 6 barriers per chunk (17 in round 1).  The weight-gradient GEMMs (k = sample index) read BOTH operands with one wide
+//     P5  dW1 += dZ1^T X;  dX = W1^T dZ1 -> its own buffer (over H1 | H2)                        MFMA (two GEMMs)
+//     P6  dfeat = dX[:, :D] + PE'(feat) . dX[:, PE cols];  V (DMA -> LDS, over dZ1)
+//     P7  dV = B^T dfeat -> straight from the accumulators to dv_out;  dB += dfeat^T V;  next chunk's requests
+// 5 barriers per chunk (17 in round 1).  The weight-gradient GEMMs (k = sample index) read BOTH operands with one wide
 // LDS read per lane and 4 samples: lane (r, kq) reads E consecutive columns of row 4t + kq, element e of operand A
 // against element e' of operand B feeds accumulator tile (e, e') — rows E_a i + e, columns E_b j + e' of the product —
-// so one b128 + one b64 read feed 8 MFMAs (round 1: 36 scalar reads per 32).  The accumulators live in registers
-// across the chunks of a workgroup and are written once, in fragment order, to the workgroup's slab;
-// wslab_reduce_kernel folds the slabs and undoes the fragment order.
+// so one b128 + one b64 read feed 8 MFMAs (round 1: 36 scalar reads per 32).  The data-gradient GEMMs take their weight
+// fragments (L2) one phase ahead, before the barrier in front of them.  The accumulators of dW2, dW1, dB live in
+// registers across the chunks of a workgroup and are written once, in fragment order, to the workgroup's slab
+// (wslab_reduce_kernel folds the slabs and undoes the fragment order); dW3, db1, db2 are summed in LDS.
 #include "tf_shade.h"
 
 using namespace tf;
@@ -120,7 +119,7 @@ __host__ __device__ inline BwdLds bwd_lds(const TfShade& S) {
     L.sh = S.feature_c + 4;
     L.sf = 36;                       // dfeat rows (<= 32 used)
     const int hreg = M * (2 * L.sh > L.sx ? 2 * L.sh : L.sx);      // H1 | H2, later dX
-    const int consts = 10 * S.feature_c + 8;                        // w3 (3 F), b1, b2; sums of dW3 (3 F), db2, db1; scratch
+    const int consts = 8 * S.feature_c + 8;                         // w3 (3 F); sums of dW3 (3 F), db2, db1; scratch
     for (L.wide = 0; L.wide < 2; ++L.wide) {
         const int vreg = M * (L.wide || L.sh > L.sv ? L.sh : L.sv);   // dZ1, later V (narrow)
         L.offV = 0;
@@ -246,9 +245,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
     float* Fd = lds + L.offF;             // dfeat [64][sf]
     float* dO = lds + L.offDo;            // [64][4]
     float* cw3 = lds + L.offC;            // [3][FC]
-    float* cb1 = cw3 + 3 * FCc;
-    float* cb2 = cb1 + FCc;
-    float* sW3 = cb2 + FCc;               // [3][FC] dW3, [FC] db2, [FC] db1: this workgroup's sums over its chunks
+    float* sW3 = cw3 + 3 * FCc;           // [3][FC] dW3, [FC] db2, [FC] db1: this workgroup's sums over its chunks
     float* sb2 = sW3 + 3 * FCc;
     float* sb1 = sb2 + FCc;
     float* cred = sb1 + FCc;              // [8] reduction scratch
@@ -270,8 +267,13 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
     f32x4 aW1[EA1][NTW];
     zero_acc(aW1);
     f32x4 aB[KTBW][NB];
-    zero_acc(aB);
+#pragma unroll
+    for (int k = 0; k < KTBW; ++k)
+#pragma unroll
+        for (int e = 0; e < NB; ++e) aB[k][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float ab3 = 0.f;
+    float tW3[3] = {0.f, 0.f, 0.f}, tb2 = 0.f;      // dW3 / db2 of thread (feature tid % FC, sample slice tid / FC)
+    float ab1[4] = {0.f, 0.f, 0.f, 0.f};             // db1 of this lane's 4 features (accumulator layout), all chunks
 
     if (tid0 == 0) {
         int run = 0;
@@ -283,34 +285,34 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
     }
     for (int i = tid0; i < 3 * FCc; i += NT) cw3[i] = S.w3[i];
     for (int i = tid0; i < 5 * FCc; i += NT) sW3[i] = 0.f;
-    if (tid0 < FCc) {
-        cb1[tid0] = S.b1[tid0];
-        cb2[tid0] = S.b2[tid0];
-    }
     __syncthreads();
     const int q_wg = samples_per_wg(pre[TF_N_SHARDS], (int)gridDim.x);
     const int v_end = min(pre[TF_N_SHARDS], ((int)blockIdx.x + 1) * q_wg);
 
     // ---- operands of the NEXT chunk, requested while the current one is processed: the X rows travel global -> LDS
     // by DMA (no registers); thread (sample tid>>2, channel tid&3) holds dL/dc and the forward's colour
-    const int sxq = L.sx >> 2, svq = L.sv >> 2;
-    const float inv_sxq = 1.f / (float)sxq, inv_svq = 1.f / (float)svq;
+    const int sxq = L.sx >> 2, svq = L.sv >> 2, shq = L.sh >> 2;
+    const float inv_sxq = 1.f / (float)sxq, inv_svq = 1.f / (float)svq, inv_shq = 1.f / (float)shq;
     float n_g = 0.f, n_c = 0.f;
     auto fetch_x = [&](const Chunk& ck, int tid, bool dma) {
         const int n = ck.n();
-        if (dma)
-            dma_rows(xs, xq4, X, sxq, inv_sxq, n, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63,
-                     [&](int r) { return ck.at(r); });
-        n_g = n_c = 0.f;
+        n_g = n_c = 0.f;        // (requested ahead of the DMA pieces: P1 needs them first)
         if (tid < 4 * M && (tid & 3) < 3 && (tid >> 2) < n) {
             const size_t p = ck.at(tid >> 2) * 3 + (tid & 3);
             n_g = grad_rgb[p];
             n_c = G.rgb_fwd[p];
         }
+        if (dma) {      // in the order the phases need them: H2 (P3), H1 (P4), X (P5)
+            const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
+            dma_rows(G.h2_saved, FCc / 4, H2, shq, inv_shq, n, w, l, [&](int r) { return ck.at(r); });
+            dma_rows(G.h1_saved, FCc / 4, H1, shq, inv_shq, n, w, l, [&](int r) { return ck.at(r); });
+            dma_rows(xs, xq4, X, sxq, inv_sxq, n, w, l, [&](int r) { return ck.at(r); });
+        }
     };
     // rows past a chunk's end keep what the previous chunk left there: finite, and multiplied by dZ = 0.  Before the
     // first chunk the X region (and, for the scalar V path, nothing else) must not hold NaN bit patterns
     for (int i = tid0; i < M * L.sx; i += NT) X[i] = 0.f;
+    for (int i = tid0; i < L.offX - L.offH; i += NT) H1[i] = 0.f;
     if (!WIDE || true) {
         for (int i = tid0; i < (WIDE ? L.offF : M * L.sv); i += NT) V[i] = 0.f;      // V / dZ1 region likewise
     }
@@ -336,85 +338,42 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         const int my_ft = wave % FT, my_sg = wave / FT, s_base = my_sg * NSW * 16;
         const int lc = lane & 15, lg = lane >> 4;
 
-        // ================= P1: do into LDS; the X rows requested during the previous chunk's P7 have landed =========
+        // ================= P1: do into LDS; the rows requested during the previous chunk's P7 have landed =========
         if (tid < 4 * M) {
             const float d = n_g * (n_c * (1.f - n_c));       // dL/dc . sigmoid'   (mlp.py:67)
             dO[tid] = (tid & 3) < 3 ? d : 0.f;
             ab3 += d;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of X are in LDS
-        f32x4 fr1[2 * NTW][1];                                // weight fragments of P2, in flight across the barrier
-#ifndef TF_X_LATE1
-        load_a_frags<1, 2 * NTW>(S.w1, kp1, 16 * my_ft, kt1, lane, fr1);
-#endif
+        f32x4 fr3[FT][1];                                    // weight fragments of P4, in flight across two barriers
+        load_a_frags<1, FT>(S.w2t, FCc, 16 * my_ft, FT, lane, fr3);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(FT) : "memory");     // this wave's DMA pieces of H2, H1, X are in LDS
         lds_barrier();
         TF_MARK(0);
-#ifdef TF_X_LATE1
-        load_a_frags<1, 2 * NTW>(S.w1, kp1, 16 * my_ft, kt1, lane, fr1);
-#endif
 
-        // ================= P2: layer 1 -> H1 =================
-        f32x4 fr2[FT][1];
-        {
-            f32x4 acc[1][NSW];
-            zero_acc(acc);
-            mma_frags<1, NSW, 2 * NTW>(fr1, X, L.sx, s_base, kt1, acc, lane);
-            load_a_frags<1, FT>(S.w2, FCc, 16 * my_ft, FT, lane, fr2);      // P3's weights: behind this epilogue + barrier
-            const int f = 16 * my_ft + 4 * lg;
-            const f32x4 bias = *reinterpret_cast<const f32x4*>(cb1 + f);
+        // ================= P3: dW3 += do^T H2, dZ2 = (do W3) . [H2 > 0] in place of H2, db2 += dZ2 =================
+        {   // thread -> (feature pf, slice of 64 / (512 / FC) samples); LDS sums (the slices of a feature meet there)
+            const int pf = tid % FCc, slice = tid / FCc;
+            constexpr int SPAN = M / (NT / FCc);
+            const float w0 = cw3[pf], w1 = cw3[FCc + pf], w2 = cw3[2 * FCc + pf];
+            constexpr int BT = SPAN < 8 ? SPAN : 8;      // samples per batch: all reads of a batch in flight together
+#pragma unroll 1
+            for (int s0 = 0; s0 < SPAN; s0 += BT) {
+                f32x4 d[BT];
+                float h[BT];
+                float* hp = H2 + (slice * SPAN + s0) * L.sh + pf;
 #pragma unroll
-            for (int j = 0; j < NSW; ++j) {
-                f32x4 h = acc[0][j] + bias;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = fmaxf(h[e], 0.f);
-                *reinterpret_cast<f32x4*>(H1 + (s_base + 16 * j + lc) * L.sh + f) = h;
-            }
-        }
-        lds_barrier();
-        TF_MARK(1);
-
-        // ================= P3: layer 2 -> H2; dW3, dZ2 (in place of H2), db2 in the epilogue =================
-        f32x4 fr3[FT][1];
-        {
-            f32x4 acc[1][NSW];
-            zero_acc(acc);
-            mma_frags<1, NSW, FT>(fr2, H1, L.sh, s_base, FT, acc, lane);
-            load_a_frags<1, FT>(S.w2t, FCc, 16 * my_ft, FT, lane, fr3);     // P4's weights
-            const int f = 16 * my_ft + 4 * lg;
-            const f32x4 bias = *reinterpret_cast<const f32x4*>(cb2 + f);
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(cw3 + f);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(cw3 + FCc + f);
-            const f32x4 w2 = *reinterpret_cast<const f32x4*>(cw3 + 2 * FCc + f);
-            float aW3[3][4], ab2[4];          // this chunk's, this lane's samples
-#pragma unroll
-            for (int e = 0; e < 4; ++e) aW3[0][e] = aW3[1][e] = aW3[2][e] = ab2[e] = 0.f;
-#pragma unroll
-            for (int j = 0; j < NSW; ++j) {
-                const int s = s_base + 16 * j + lc;
-                const f32x4 d = *reinterpret_cast<const f32x4*>(dO + 4 * s);
-                f32x4 dz;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float h = fmaxf(acc[0][j][e] + bias[e], 0.f);
-                    aW3[0][e] = fmaf(d[0], h, aW3[0][e]);
-                    aW3[1][e] = fmaf(d[1], h, aW3[1][e]);
-                    aW3[2][e] = fmaf(d[2], h, aW3[2][e]);
-                    dz[e] = h > 0.f ? fmaf(d[2], w2[e], fmaf(d[1], w1[e], d[0] * w0[e])) : 0.f;
-                    ab2[e] += dz[e];
+                for (int i = 0; i < BT; ++i) {
+                    d[i] = *reinterpret_cast<const f32x4*>(dO + 4 * (slice * SPAN + s0 + i));
+                    h[i] = hp[i * L.sh];
                 }
-                *reinterpret_cast<f32x4*>(H2 + s * L.sh + f) = dz;
-            }
-            // sums over the 16 sample lanes (DPP), then one LDS add per feature: the per-feature vectors would cost
-            // 20 registers per lane if they stayed in registers across the chunks
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v0 = row16_sum(aW3[0][e]), v1 = row16_sum(aW3[1][e]), v2 = row16_sum(aW3[2][e]);
-                const float v3 = row16_sum(ab2[e]);
-                if (lc == 0) {
-                    atomicAdd(sW3 + f + e, v0);
-                    atomicAdd(sW3 + FCc + f + e, v1);
-                    atomicAdd(sW3 + 2 * FCc + f + e, v2);
-                    atomicAdd(sb2 + f + e, v3);
+                for (int i = 0; i < BT; ++i) {
+                    tW3[0] = fmaf(d[i][0], h[i], tW3[0]);
+                    tW3[1] = fmaf(d[i][1], h[i], tW3[1]);
+                    tW3[2] = fmaf(d[i][2], h[i], tW3[2]);
+                    const float dz = h[i] > 0.f ? fmaf(d[i][2], w2, fmaf(d[i][1], w1, d[i][0] * w0)) : 0.f;
+                    hp[i * L.sh] = dz;
+                    tb2 += dz;
                 }
             }
         }
@@ -429,7 +388,6 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
             mma_frags<1, NSW, FT>(fr3, H2, L.sh, s_base, FT, acc, lane);
             if (wave < 2 * kt1) load_a_frags<1, FT>(S.w1t, FCc, 16 * (wave >> 1), FT, lane, frx[0]);
             const int f = 16 * my_ft + 4 * lg;
-            float ab1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < NSW; ++j) {
                 const int s = s_base + 16 * j + lc;
@@ -442,11 +400,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                 }
                 *reinterpret_cast<f32x4*>(DZ1 + s * L.sh + f) = dz;
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v4 = row16_sum(ab1[e]);
-                if (lc == 0) atomicAdd(sb1 + f + e, v4);
-            }
+
             TF_MARK(3);
             // dW2[f2][f1]: wave -> (f2 block of FC/2, f1 block of FC/4)
             tn_block<EA2, EB2>(H2, L.sh, (FCc / 2) * (wave >> 2), H1, L.sh, (FCc / 4) * (wave & 3), M / 4, aW2, lane);
@@ -551,20 +505,14 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of V are in LDS
         // basis fragments of the wave's first dV unit (P7), in flight across the barrier
-        const int g4 = ktB >> 2, n_units = 4 * (g4 + (ktB & 3));
+        const int n_units = 4 * ((ktB + 3) >> 2);
         f32x4 bfr[4 * NB];
         {
             const int u0 = NW - 1 - wave, r = lane & 15, kq = lane >> 4;
-            const bool full = (u0 >> 2) < g4;
-            const float* np = S.basis + (size_t)kq * kpB + (full ? 64 * (u0 >> 2) + 4 * r : 64 * g4 + 16 * ((u0 >> 2) - g4) + r);
+            const float* np = S.basis + (size_t)kq * kpB + 64 * (u0 >> 2) + 4 * r;
 #pragma unroll
-            for (int t = 0; t < 4 * NB; ++t) {
-                bfr[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (u0 < n_units) {
-                    if (full) bfr[t] = *reinterpret_cast<const f32x4*>(np + (size_t)4 * t * kpB);
-                    else bfr[t][0] = np[(size_t)4 * t * kpB];
-                }
-            }
+            for (int t = 0; t < 4 * NB; ++t)
+                bfr[t] = u0 < n_units ? *reinterpret_cast<const f32x4*>(np + (size_t)4 * t * kpB) : (f32x4){0.f, 0.f, 0.f, 0.f};
             __builtin_amdgcn_sched_barrier(0);
         }
         lds_barrier();
@@ -582,104 +530,66 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
             else n_g = n_c = 0.f;
         }
 
+        TF_MARK(10);
         // ================= P7: dV = B^T dfeat -> dv_out;  dB += dfeat^T V =================
-        {   // dV[s][c] = sum_f B[f][c] dfeat[s][f]: units (group of 4 column tiles | single tile, sample tile), dealt from
-            // the last wave down (the low waves own the extra dB tiles).  A = packed basis rows f (k index), read
-            // 4 columns per lane (its fragments `bfr` were requested before P6's barrier; the next unit's replace them
-            // k-step by k-step behind the MFMAs that consumed them); B = Fd[s][f].  The accumulators go straight to
-            // dv_out, ahead of the dB loop, so that the stores have retired when the next chunk waits for its X rows.
+        {   // dV[s][c] = sum_f B[f][c] dfeat[s][f]: units (group of 4 column tiles, sample tile), dealt from the last
+            // wave down (the low waves own the extra dB tiles).  A = packed basis rows f (k index), read 4 columns per
+            // lane (the first unit's fragments `bfr` were requested before P6's barrier; the next unit's replace them
+            // behind the MFMAs); B = Fd[s][f].  The last group may reach past the packed row (TfShade.basis carries 64
+            // floats of tail padding): those columns are computed and dropped.  The accumulators go straight to dv_out,
+            // ahead of the dB loop, so that the stores have retired when the next chunk waits for its X rows.
             const int r = lane & 15, kq = lane >> 4;
+#ifdef TF_X_NODV
+            if (0)
+#endif
             for (int u = NW - 1 - wave; u < n_units; u += NW) {
-                const int st = u & 3, grp = u >> 2, un = u + NW;
+                const int st = u & 3, cb = 64 * (u >> 2), un = u + NW;
                 const float* bp = Fd + (16 * st + r) * L.sf + kq;
                 const int s = 16 * st + lc;
-                const bool nxt = un < n_units, nxt_full = (un >> 2) < g4;
-                const float* np = S.basis + (size_t)kq * kpB + (nxt_full ? 64 * (un >> 2) + 4 * r : 64 * g4 + 16 * ((un >> 2) - g4) + r);
-                if (grp < g4) {
-                    const int cb = 64 * grp;
-                    f32x4 acc[4];
+                float bq[4 * NB];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < 4 * NB; ++t) bq[t] = bp[4 * t];
+                f32x4 acc[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (un < n_units) {     // the next unit's fragments replace this unit's, k-step by k-step
+                    const float* np = S.basis + (size_t)kq * kpB + 64 * (un >> 2) + 4 * r;
 #pragma unroll
                     for (int t = 0; t < 4 * NB; ++t) {
                         const f32x4 a = bfr[t];
-                        const float b = bp[4 * t];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b, acc[e], 0, 0, 0);
-                        if (nxt) {
-                            if (nxt_full) bfr[t] = *reinterpret_cast<const f32x4*>(np + (size_t)4 * t * kpB);
-                            else bfr[t][0] = np[(size_t)4 * t * kpB];
-                        }
-                    }
-                    if (s < n) {     // element (e, reg): column cb + 4 (4 lg + reg) + e
-                        float* o = dv + ck.at(s) * nat;
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) {
-                            const int c = cb + 16 * lg + 4 * reg;
-                            if (v_vec && c + 3 < nat) {
-                                *reinterpret_cast<f32x4*>(o + c) = (f32x4){acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]};
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                    if (c + e < nat) o[c + e] = acc[e][reg];
-                            }
-                        }
+                        for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bq[t], acc[e], 0, 0, 0);
+                        bfr[t] = *reinterpret_cast<const f32x4*>(np + (size_t)4 * t * kpB);
                     }
                 } else {
-                    const int cb = 64 * g4 + 16 * (grp - g4);
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int t = 0; t < 4 * NB; ++t) {
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[t][0], bp[4 * t], acc, 0, 0, 0);
-                        if (nxt) {
-                            if (nxt_full) bfr[t] = *reinterpret_cast<const f32x4*>(np + (size_t)4 * t * kpB);
-                            else bfr[t][0] = np[(size_t)4 * t * kpB];
-                        }
-                    }
-                    if (s < n) {     // element reg: column cb + 4 lg + reg
-                        float* o = dv + ck.at(s) * nat;
-                        const int c = cb + 4 * lg;
+                    for (int t = 0; t < 4 * NB; ++t)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[t][e], bq[t], acc[e], 0, 0, 0);
+                }
+                if (s < n) {     // element (e, reg): column cb + 4 (4 lg + reg) + e
+                    float* o = dv + ck.at(s) * nat;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int c = cb + 16 * lg + 4 * reg;
                         if (v_vec && c + 3 < nat) {
-                            *reinterpret_cast<f32x4*>(o + c) = acc;
+                            *reinterpret_cast<f32x4*>(o + c) = (f32x4){acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]};
                         } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                if (c + e < nat) o[c + e] = acc[e];
+                                if (c + e < nat) o[c + e] = acc[e][reg];
                         }
                     }
                 }
             }
         }
         TF_MARK(8);
-        {   // dB[f][c]: A = Fd (NB elements per lane: f = NB i + e), B = V column tiles wave, wave + 8, wave + 16;
-            // both from LDS, fetched one k-step ahead
-            const int r = lane & 15, kq = lane >> 4;
-            const float* ap = Fd + kq * L.sf + NB * r;
-            const float* bp = V + kq * L.sv + 16 * wave + r;
-            float a[NB], b[KTBW];
-            ldv<NB>(ap, a);
+        // dB[f][c] += sum_s dfeat[s][f] V[s][c]: A = Fd (NB elements per lane: f = NB i + e), B = V column tiles wave,
+        // wave + 8, wave + 16 — one pipelined loop per tile the wave owns
 #pragma unroll
-            for (int k = 0; k < KTBW; ++k) b[k] = wave + NW * k < ktB ? bp[128 * k] : 0.f;
-#pragma unroll
-            for (int t = 0; t < M / 4; ++t) {
-                float an[NB], bn[KTBW];
-                const int tn = t + 1 < M / 4 ? t + 1 : t;
-                ldv<NB>(ap + 4 * tn * L.sf, an);
-#pragma unroll
-                for (int k = 0; k < KTBW; ++k) bn[k] = wave + NW * k < ktB ? bp[4 * tn * L.sv + 128 * k] : 0.f;
-#pragma unroll
-                for (int k = 0; k < KTBW; ++k) {
-                    if (wave + NW * k < ktB) {
-#pragma unroll
-                        for (int e = 0; e < NB; ++e)
-                            aB[k][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[k], aB[k][e], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < NB; ++e) a[e] = an[e];
-#pragma unroll
-                for (int k = 0; k < KTBW; ++k) b[k] = bn[k];
-            }
+        for (int k = 0; k < KTBW; ++k) {
+            f32x4 (&tile)[NB][1] = reinterpret_cast<f32x4 (&)[NB][1]>(aB[k]);
+            if (wave + NW * k < ktB) tn_block<NB, 1>(Fd, L.sf, 0, V, L.sv, 16 * (wave + NW * k), M / 4, tile, lane);
         }
         first = false;
         TF_MARK(9);
@@ -687,8 +597,11 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         if (WIDE) {
             lds_barrier();
             Chunk c1;
-            if (locate_chunk(src, pre, v, v_end, c1))
+            if (locate_chunk(src, pre, v, v_end, c1)) {
+                dma_rows(G.h2_saved, FCc / 4, H2, shq, inv_shq, c1.n(), wave, lane, [&](int r) { return c1.at(r); });
+                dma_rows(G.h1_saved, FCc / 4, H1, shq, inv_shq, c1.n(), wave, lane, [&](int r) { return c1.at(r); });
                 dma_rows(xs, xq4, X, sxq, inv_sxq, c1.n(), wave, lane, [&](int r) { return c1.at(r); });
+            }
         }
     }
     TF_FLUSH();
@@ -722,6 +635,19 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
     }
     // ================= the per-feature vectors (summed in LDS over this workgroup's chunks): one atomic per entry ======
     {
+        {   // the threads' / lanes' sums meet in LDS (once per workgroup)
+            const int pf = tid3 % FCc, lane = tid3 & 63, lc = lane & 15;
+            const int f = 16 * ((tid3 >> 6) % FT) + 4 * (lane >> 4);
+            atomicAdd(sW3 + pf, tW3[0]);
+            atomicAdd(sW3 + FCc + pf, tW3[1]);
+            atomicAdd(sW3 + 2 * FCc + pf, tW3[2]);
+            atomicAdd(sb2 + pf, tb2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v4 = row16_sum(ab1[e]);
+                if (lc == 0) atomicAdd(sb1 + f + e, v4);
+            }
+        }
         __syncthreads();
         for (int i = tid3; i < 3 * FCc; i += NT) atomicAdd(G.w3 + i, sW3[i]);
         if (tid3 < FCc) {
@@ -907,6 +833,14 @@ int tf_debug_phase_cycles_bwd(unsigned long long* out16, int reset) {
     if (e == hipSuccess && reset) {
         unsigned long long z[16] = {0};
         e = hipMemcpyToSymbol(HIP_SYMBOL(tf_phase_cycles), z, sizeof(z));
+    }
+    return (int)e;
+}
+int tf_debug_phase_cycles_bwd_w4(unsigned long long* out16, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(tf_phase_cycles_w4), sizeof(unsigned long long) * 16);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(tf_phase_cycles_w4), z, sizeof(z));
     }
     return (int)e;
 }

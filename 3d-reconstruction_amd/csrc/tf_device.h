@@ -30,7 +30,9 @@ static __device__ int tf_dbg_flags;
 static __device__ unsigned long long tf_phase_cycles[16];
 #define TF_T0() unsigned long long _t = __builtin_readcyclecounter(); unsigned long long _ph[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}
 #define TF_MARK(i) do { unsigned long long _n = __builtin_readcyclecounter(); _ph[i] += _n - _t; _t = _n; } while (0)
-#define TF_FLUSH() do { if (threadIdx.x == 0) for (int _i = 0; _i < 16; ++_i) atomicAdd(&tf_phase_cycles[_i], _ph[_i]); } while (0)
+static __device__ unsigned long long tf_phase_cycles_w4[16];      // the same, seen by wave 4 (thread 256)
+#define TF_FLUSH() do { if (threadIdx.x == 0) for (int _i = 0; _i < 16; ++_i) atomicAdd(&tf_phase_cycles[_i], _ph[_i]); \
+                        if (threadIdx.x == 256) for (int _i = 0; _i < 16; ++_i) atomicAdd(&tf_phase_cycles_w4[_i], _ph[_i]); } while (0)
 #else
 #define TF_T0()
 #define TF_MARK(i)

@@ -171,11 +171,11 @@ class _Workspace:
         if save_valid:
             spec += [("val_idx", R * N, torch.int32), ("val_feat", R * N, torch.float32),
                      ("grad_rgb", cap * 3, torch.float32), ("rgb_pre", R * 3, torch.float32)]
-            n_app, wslab, kp_in = train_extra
+            n_app, wslab, kp_in, fc = train_extra
             # dv: plane*line product rows saved by the forward, replaced by dL/dV rows in the backward; xs: the MLP
             # input rows saved by the forward (TfShadeSave)
             spec += [("dv", cap * n_app, torch.float32), ("wslab", wslab, torch.float32),
-                     ("xs", cap * kp_in, torch.float32)]
+                     ("xs", cap * kp_in, torch.float32), ("h1s", cap * fc, torch.float32), ("h2s", cap * fc, torch.float32)]
             if binned is not None:   # binned gradient scatter (csrc/bin.hip): entry lists + sort workspace
                 nkeys, kpe = max(binned[0], binned[1]), binned[2]
                 n_ints = 4 * (nkeys + 8) + kpe * cap // 256 + 64
@@ -415,8 +415,10 @@ class TensorBase(nn.Module):
                 out.append(hit[1])   # (while a graph is being captured the pack launch must be part of the graph)
                 continue
             shape = (kp, rows_pad) if transpose else (rows_pad, kp)
-            dst = hit[1] if hit is not None and tuple(hit[1].shape) == shape else \
-                torch.empty(shape, dtype=torch.float32, device=src.device)
+            if hit is not None and tuple(hit[1].shape) == shape:
+                dst = hit[1]
+            else:   # 64 floats of tail padding: tf_shade_backward reads the packed basis in whole 64-column groups
+                dst = torch.zeros(shape[0] * shape[1] + 64, dtype=torch.float32, device=src.device)[:shape[0] * shape[1]].view(shape)
             todo.append((src.detach().contiguous(), dst, rows, cols, rows_pad, transpose))
             self._pack_cache[key] = (tag, dst)
             out.append(dst)
@@ -587,7 +589,9 @@ class TensorBase(nn.Module):
                         f"app_dim={self.app_dim} (<= 32), MLP input {sh.in_c} (<= 192), sum(app_n_comp)="
                         f"{self._n_app_total()} (<= 384, and the 64-sample tile must fit the 160 KB of LDS)")
                 wslab = int(H.lib().tf_shade_backward_wslab_floats(C.byref(sh))) if sh.head == H.HEAD_MLP else 64
-                extra = (self._n_app_total(), wslab, (int(sh.in_c) + 15) // 16 * 16 if sh.head == H.HEAD_MLP else 0)
+                mlp_head = sh.head == H.HEAD_MLP
+                extra = (self._n_app_total(), wslab, (int(sh.in_c) + 15) // 16 * 16 if mlp_head else 0,
+                         int(sh.feature_c) if mlp_head else 0)
             ws = _Workspace(R, N, dev, save_valid, self._debug_masks, binned, extra)
             if not save_valid:
                 self._ws_cache = {key: ws}
@@ -674,7 +678,7 @@ class TensorBase(nn.Module):
         save = None
         if save_valid and shade.head == H.HEAD_MLP:      # rows the backward streams back instead of recomputing them
             save = H.TfShadeSave()
-            save.x, save.v = ws.xs.data_ptr(), ws.dv.data_ptr()
+            save.x, save.v, save.h1, save.h2 = ws.xs.data_ptr(), ws.dv.data_ptr(), ws.h1s.data_ptr(), ws.h2s.data_ptr()
         self._timed("tf_shade_forward", lib.tf_shade_forward, C.byref(shade), rays.data_ptr(), int(bool(ndc_ray)),
                     ws.counters.data_ptr(), ws.seg_cap, ws.app_ray.data_ptr(), ws.app_xyz.data_ptr(),
                     ws.rgb.data_ptr(), self.shade_wgs_beside_sort if sorted_on is not None else 0,

@@ -133,7 +133,8 @@ typedef struct TfShade {
     int app_dim;
     int n_app_total;       /* sum of n_comp (VM) or n_comp[0] (CP) */
     int head;              /* TF_HEAD_* */
-    const float* basis;    /* packed basis_mat: [roundup16(app_dim)][kpad(n_app_total)]   tensoRF.py:149,263 */
+    const float* basis;    /* packed basis_mat: [roundup16(app_dim)][kpad(n_app_total)]   tensoRF.py:149,263; training:
+                            * followed by >= 64 readable floats (tf_shade_backward reads whole 64-column groups) */
     int n_pe;
     TfPeBlock pe[3];
     int in_c;              /* MLP input width (mlp.py:31,75,113) */
@@ -194,6 +195,8 @@ int tf_march_forward(const TfField* field, const TfMarchIO* io, tf_stream_t stre
 typedef struct TfShadeSave {  /* training: rows kept for tf_shade_backward (both NULL in inference) */
     float* x;              /* (cap, kpad(in_c)): MLP input [feat, view, PE blocks] of every packed sample, zero padded */
     float* v;              /* (cap, n_app_total): plane*line products (the operand of basis_mat, tensoRF.py:263) */
+    float* h1;             /* (cap, feature_c): first hidden layer after ReLU  (mlp.py:34-35) */
+    float* h2;             /* (cap, feature_c): second hidden layer after ReLU (mlp.py:36-37) */
 } TfShadeSave;
 int tf_shade_forward(const TfShade* shade, const float* rays, int ndc, const int* counters, int seg_cap,
                      const int* app_ray, const float* app_xyz, float* rgb_out, int max_workgroups,
@@ -221,10 +224,10 @@ int tf_march_backward(const TfField* field, const TfMarchIO* io, const float* gr
  * density sample with a non-zero gradient to the sharded entry list (counter slot 3) for tf_binned_scatter.
  * When io->ent_offset is set the forward has already placed the entries (TfMarchIO.ent_xyz): only ent_df is written. */
 
-/* Backward of the shading head + appearance lookup (autograd of tensoRF.py:230-263, mlp.py:27-155): re-runs the two
- * hidden layers of each 64-sample chunk on the rows the training forward saved (TfShadeSave: MLP inputs and
- * plane*line products; the colours are the forward's rgb_out), then accumulates gradients of w1,b1,w2,b2,w3,b3,
- * basis and the appearance factors.  Gradient matrices use the reference's own (unpadded, row-major) layouts. */
+/* Backward of the shading head + appearance lookup (autograd of tensoRF.py:230-263, mlp.py:27-155) on the rows the
+ * training forward saved (TfShadeSave: MLP inputs, both hidden layers and the plane*line products; the colours are
+ * the forward's rgb_out) — nothing of the forward is recomputed: accumulates gradients of w1,b1,w2,b2,w3,b3, basis
+ * and the appearance factors.  Gradient matrices use the reference's own (unpadded, row-major) layouts. */
 typedef struct TfShadeGrads {
     float* w1; float* b1; float* w2; float* b2; float* w3; float* b3;
     float* basis;          /* (app_dim, n_app_total) */
@@ -235,6 +238,8 @@ typedef struct TfShadeGrads {
     int direct_scatter;    /* 1: scatter dv_out with per-tap atomics inside the call (TensorCP / binning disabled);
                             * 0: the caller runs tf_binned_scatter on dv_out */
     const float* x_saved;  /* (cap, kpad(in_c)): MLP input rows saved by the forward (TfShadeSave.x) */
+    const float* h1_saved; /* (cap, feature_c): TfShadeSave.h1 */
+    const float* h2_saved; /* (cap, feature_c): TfShadeSave.h2 */
     const float* rgb_fwd;  /* (cap, 3): the forward's rgb_out (sigmoid outputs) */
 } TfShadeGrads;
 size_t tf_shade_backward_wslab_floats(const TfShade* shade);

@@ -1,6 +1,6 @@
 """Diagnostic: per-phase shader cycles of the shade backward kernel (TF_DIAG=1 build)."""
 import os, sys, ctypes
-os.environ["TF_DIAG"] = "1"
+os.environ.setdefault("TF_DIAG", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import recon_amd
@@ -18,6 +18,7 @@ perm = torch.randperm(rays.shape[0], generator=torch.Generator().manual_seed(1))
 batches = [rays[perm[i * R:(i + 1) * R]].contiguous() for i in range(4)]
 lib = recon_amd._hip.lib()
 out = (ctypes.c_ulonglong * 16)()
+out4 = (ctypes.c_ulonglong * 16)()
 if len(sys.argv) > 1:
     lib.tf_debug_set_bwd_wgs(int(sys.argv[1]))
 tgt = torch.rand(R, 3, device=dev)
@@ -29,10 +30,12 @@ for rep in range(2):
         loss.backward()
     torch.cuda.synchronize()
     lib.tf_debug_phase_cycles_bwd(out, 1)
-names = ["P1 X,dO->LDS", "P2 layer1", "P3 layer2+dZ2", "P4a dH1->dZ1", "P4b dW2", "P5a dW1", "P5b dX", "P6 dfeat,V->LDS",
-         "P7a dB", "P7b dV"]
+    lib.tf_debug_phase_cycles_bwd_w4(out4, 1)
+names = ["P1 wait rows, dO", "-", "P3 dZ2 pass", "P4a dH1->dZ1", "P4b dW2", "P5a dW1", "P5b dX", "P6 dfeat,V->LDS",
+         "P7a dV", "P7b dB", "P7 next-chunk requests"]
 tot = sum(out[i] for i in range(len(names)))
 ntile = sum((int(c) + 63) // 64 for c in model.last["ws"].counters2d[:, 0].tolist())
 print("tiles in last batch", ntile)
 for i, n in enumerate(names):
-    print(f"{n:16s} {out[i]/4/ntile:10.0f} cycles/tile  {100*out[i]/tot:5.1f}%")
+    print(f"{n:24s} wave 0: {out[i]/4/ntile:8.0f}   wave 4: {out4[i]/4/ntile:8.0f} cycles/chunk  {100*out[i]/tot:5.1f}%")
+print(f"{'total':24s} wave 0: {tot/4/ntile:8.0f}")
