@@ -302,11 +302,12 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
             n_g = grad_rgb[p];
             n_c = G.rgb_fwd[p];
         }
-        if (dma) {      // in the order the phases need them: H2 (P3), H1 (P4), X (P5)
+        // The CU takes in ~17 B per cycle: a chunk's 105 KB of rows requested in one burst stall the requesting waves for
+        // ~6 k cycles (the queue backs up into the issue).  So each tile is requested just ahead of the phase before its
+        // first use, beside that phase's arithmetic: H2 here (P3 needs it), H1 at the start of P3 (P4), X in P4 (P5).
+        if (dma) {
             const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
             dma_rows(G.h2_saved, FCc / 4, H2, shq, inv_shq, n, w, l, [&](int r) { return ck.at(r); });
-            dma_rows(G.h1_saved, FCc / 4, H1, shq, inv_shq, n, w, l, [&](int r) { return ck.at(r); });
-            dma_rows(xs, xq4, X, sxq, inv_sxq, n, w, l, [&](int r) { return ck.at(r); });
         }
     };
     // rows past a chunk's end keep what the previous chunk left there: finite, and multiplied by dZ = 0.  Before the
@@ -346,11 +347,12 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         }
         f32x4 fr3[FT][1];                                    // weight fragments of P4, in flight across two barriers
         load_a_frags<1, FT>(S.w2t, FCc, 16 * my_ft, FT, lane, fr3);
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(FT) : "memory");     // this wave's DMA pieces of H2, H1, X are in LDS
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(FT) : "memory");     // this wave's DMA pieces of H2 are in LDS
         lds_barrier();
         TF_MARK(0);
 
         // ================= P3: dW3 += do^T H2, dZ2 = (do W3) . [H2 > 0] in place of H2, db2 += dZ2 =================
+        dma_rows(G.h1_saved, FCc / 4, H1, shq, inv_shq, n, wave, lane, [&](int r) { return ck.at(r); });     // for P4
         {   // thread -> (feature pf, slice of 64 / (512 / FC) samples); LDS sums (the slices of a feature meet there)
             const int pf = tid % FCc, slice = tid / FCc;
             constexpr int SPAN = M / (NT / FCc);
@@ -377,6 +379,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                 }
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of H1 are in LDS
         lds_barrier();
         TF_MARK(2);
 
@@ -402,9 +405,11 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
             }
 
             TF_MARK(3);
+            dma_rows(xs, xq4, X, sxq, inv_sxq, n, wave, lane, [&](int r) { return ck.at(r); });     // for P5, lands behind dW2
             // dW2[f2][f1]: wave -> (f2 block of FC/2, f1 block of FC/4)
             tn_block<EA2, EB2>(H2, L.sh, (FCc / 2) * (wave >> 2), H1, L.sh, (FCc / 4) * (wave & 3), M / 4, aW2, lane);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of X are in LDS
         lds_barrier();
         TF_MARK(4);
 
@@ -597,11 +602,8 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         if (WIDE) {
             lds_barrier();
             Chunk c1;
-            if (locate_chunk(src, pre, v, v_end, c1)) {
+            if (locate_chunk(src, pre, v, v_end, c1))
                 dma_rows(G.h2_saved, FCc / 4, H2, shq, inv_shq, c1.n(), wave, lane, [&](int r) { return c1.at(r); });
-                dma_rows(G.h1_saved, FCc / 4, H1, shq, inv_shq, c1.n(), wave, lane, [&](int r) { return c1.at(r); });
-                dma_rows(xs, xq4, X, sxq, inv_sxq, c1.n(), wave, lane, [&](int r) { return c1.at(r); });
-            }
         }
     }
     TF_FLUSH();

@@ -109,13 +109,15 @@ def kernel_table(events, stats, cfg):
     R, Sb, Ss, Sa = stats["rays"], stats["bbox"], stats["density"], stats["shaded"]
     cd, ca = sum(cfg["density_n_comp"]), sum(cfg["app_n_comp"])
     mlp_flops = 2 * (cfg["in_c"] * cfg["featureC"] + cfg["featureC"] ** 2 + cfg["featureC"] * 3) + 2 * ca * cfg["app_dim"]
-    bwd_flops = 2 * mlp_flops + mlp_flops      # weight-gradient + input-gradient GEMMs + forward recompute
+    bwd_flops = 2 * mlp_flops                  # weight-gradient + input-gradient GEMMs (the forward's rows are saved, not
+    #                                            recomputed: round 1 re-ran the forward in the kernel and counted 3 x)
     algo = {
         "tf_march_forward": (R * 40 + 32 * Sb + 24 * cd * Ss, 0.0),
         "tf_shade_forward": (24 * ca * Sa, mlp_flops * Sa),
         "tf_composite_forward": (R * 16 + 16 * Sa, 0.0),
         "tf_march_backward": (2 * 24 * cd * Ss + 8 * Ss, 0.0),
-        "tf_shade_backward": (2 * 24 * ca * Sa, bwd_flops * Sa),
+        # reads: saved X, H1, H2, V rows + colours; writes dL/dV rows (the appearance taps move in tf_binned_scatter_app)
+        "tf_shade_backward": ((4 * (cfg["in_c"] + 2 * cfg["featureC"] + 2 * ca) + 24) * Sa, bwd_flops * Sa),
     }
     out = {}
     for name, pairs in events.items():
