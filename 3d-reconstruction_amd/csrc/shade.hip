@@ -15,30 +15,71 @@ using namespace tf;
 
 namespace {
 
-// training: copy a [n][w] row block of an LDS tile (row stride ld floats, w a multiple of 4) to global rows, 16 B per lane
-template <int NT>
-__device__ __forceinline__ void save_rows(float* dst, const float* tile, int ld, int w, int n, int tid) {
+// The packed sample list is cut EVENLY over the persistent workgroups (workgroup w owns samples [w q, (w+1) q) of the
+// shards' concatenation, q = max(64, ceil(S / workgroups))) and walked in chunks of <= 64; a chunk may straddle a shard
+// boundary, so it has two pieces.  (Round 1 handed out whole tiles through an atomic ticket: 11 k cycles per tile went
+// into that dependent atomic + counter read, and nothing of the next tile could be requested ahead.)
+struct FChunk {
+    int s0, n0, s1, n1;
+    __device__ __forceinline__ int n() const { return n0 + n1; }
+    __device__ __forceinline__ size_t at(int k) const { return k < n0 ? (size_t)s0 + k : (size_t)s1 + (k - n0); }
+};
+__device__ __forceinline__ int fwd_samples_per_wg(int total, int n_wg) {
+    const int q = (total + n_wg - 1) / n_wg;
+    return q < M ? M : q;
+}
+// spre: exclusive prefix of the shards' sample counts (65 entries) — or NULL for a plain point list of n_direct entries
+__device__ __forceinline__ bool fwd_locate(const TileSrc& src, const int* spre, int v, int v_end, FChunk& c) {
+    c.s0 = c.n0 = c.s1 = c.n1 = 0;
+    if (v >= v_end) return false;
+    const int want = min(M, v_end - v);
+    if (src.counters == nullptr) {
+        c.s0 = v;
+        c.n0 = want;
+        return true;
+    }
+    static_assert(TF_N_SHARDS == 64, "one shard per lane");
+    const int g = __builtin_popcountll(__ballot(spre[threadIdx.x & 63] <= v)) - 1;
+    c.s0 = g * src.seg_cap + (v - spre[g]);
+    c.n0 = min(want, spre[g + 1] - v);
+    if (c.n0 < want) {
+        int g2 = g + 1;
+        while (g2 < TF_N_SHARDS && spre[g2 + 1] == spre[g2]) ++g2;
+        if (g2 < TF_N_SHARDS) {
+            c.s1 = g2 * src.seg_cap;
+            c.n1 = min(want - c.n0, spre[g2 + 1] - spre[g2]);
+        }
+    }
+    return true;
+}
+
+// training: copy the first n rows (w floats each, w a multiple of 4) of an LDS tile with row stride ld to the global rows
+// at(row) * w, 16 B per lane
+template <int NT, typename AtFn>
+__device__ __forceinline__ void save_rows(float* dst, const float* tile, int ld, int w, int n, int tid, AtFn at) {
     const int w4 = w >> 2;
     const float inv = 1.f / (float)w4;
     for (int q = tid; q < n * w4; q += NT) {
         int row, c4;
         row_quad(q, w4, inv, row, c4);
-        *reinterpret_cast<f32x4*>(dst + (size_t)q * 4) = *reinterpret_cast<const f32x4*>(tile + row * ld + 4 * c4);
+        *reinterpret_cast<f32x4*>(dst + at(row) * (size_t)w + 4 * c4) = *reinterpret_cast<const f32x4*>(tile + row * ld + 4 * c4);
     }
 }
 
 // FT = feature_c / 16 hidden feature tiles (4, 8 or 16), NB = ceil(app_dim/16) basis feature tiles.
-// 512 threads = 8 waves shade one 64-sample tile; two workgroups share a CU (81,680 B of LDS each), i.e. 4 waves per
-// SIMD (<= 128 VGPRs).  A launch has only ~5 tiles per CU: the chain of dependent phases of one tile is spread over
-// 8 waves, and the two resident workgroups fill each other's barrier and memory waits.  (Measured: starting half of
-// the workgroups half a tile late to break lockstep changed nothing; issuing all taps of a sample at once made the
-// gather slower — it is bound by the CU's fetch rate from the Infinity Cache, ~11-18 B/cycle/CU.)
+// 512 threads = 8 waves shade one 64-sample chunk; two workgroups share a CU (81,680 B of LDS each), i.e. 4 waves per
+// SIMD (<= 128 VGPRs): the chain of dependent phases of one chunk is spread over 8 waves, and the two resident
+// workgroups fill each other's barrier and memory waits (the gather is bound by the CU's fetch rate from the Infinity
+// Cache, ~11-18 B/cycle/CU, whichever way its loads are issued).  The weight fragments of a hidden layer are requested
+// one phase ahead (tf_shade.h load_a_frags), the sample info of the next chunk one chunk ahead.
 // Wave w: feature tiles NFW*(w % FG) .. +NFW, sample tiles NSW*(w / FG) .. +NSW  (FG = 8 / SG feature groups).
 template <int FT, int NB>
 __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, const TileSrc src, float* __restrict__ rgb_out,
                                                                float* __restrict__ feat_out, const TfShadeSave save) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // the only LDS object (16-B aligned base)
     constexpr int NT = 512, NW = 8, SG = FT < NW ? NW / FT : 1, FG = NW / SG, NFW = FT / FG, NSW = 4 / SG;
+    constexpr bool PRE = NFW == 1;      // weight fragments of a whole layer fit the 128-register budget
+    constexpr int KG1 = 12;             // layer 1: up to 12 k-groups (in_c <= 192)
     const ShadeLds L = shade_lds(S);
     int* pre = reinterpret_cast<int*>(lds + L.offPre);
     float* regA = lds + L.offA;   // V, then H1
@@ -47,72 +88,83 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
     float* iview = lds + L.offInfo + 3 * M;  // [64][3]
     const int tid0 = threadIdx.x;
 
-    if (src.counters) {   // tile prefix over shards (every workgroup computes the same table)
+    int total = src.n_direct;
+    if (src.counters) {   // sample prefix over shards (every workgroup computes the same table)
         if (tid0 == 0) {
             int run = 0;
             for (int g = 0; g < TF_N_SHARDS; ++g) {
                 pre[g] = run;
-                run += (src.counters[g * TF_SHARD_STRIDE] + M - 1) / M;
+                run += src.counters[g * TF_SHARD_STRIDE];
             }
             pre[TF_N_SHARDS] = run;
         }
         __syncthreads();
+        total = pre[TF_N_SHARDS];
+    }
+    // whole 64-sample chunks, dealt evenly: workgroup b owns chunks [b C / W, (b + 1) C / W) of the C = ceil(total / 64)
+    const long long n_chunks = (total + M - 1) / M;
+    const int v_begin = (int)(((long long)blockIdx.x * n_chunks) / (long long)gridDim.x) * M;
+    const int v_end = min(total, (int)((((long long)blockIdx.x + 1) * n_chunks) / (long long)gridDim.x) * M);
+
+    // per-sample info of thread tid < 64, fetched for the NEXT chunk while the current one is processed
+    // (app_ray -> rays is a chain of two global latencies)
+    float nx_x[3] = {0.f, 0.f, 0.f}, nx_v[3] = {0.f, 0.f, 0.f};
+    auto fetch_info = [&](const FChunk& ck, int tid) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) nx_x[a] = nx_v[a] = 0.f;
+        if (tid < ck.n()) {
+            const size_t s = ck.at(tid);
+            nx_x[0] = src.app_xyz[s * 3]; nx_x[1] = src.app_xyz[s * 3 + 1]; nx_x[2] = src.app_xyz[s * 3 + 2];
+            if (src.rays) {
+                const float* rp = src.rays + (size_t)src.app_ray[s] * 6 + 3;
+                nx_v[0] = rp[0]; nx_v[1] = rp[1]; nx_v[2] = rp[2];
+            }
+        }
+    };
+    {
+        FChunk c1;
+        if (fwd_locate(src, pre, v_begin, v_end, c1)) fetch_info(c1, tid0);
     }
 
     TF_T0();
-    // Tiles are handed out dynamically (one returning atomic per tile on a per-launch ticket word, fetched one
-    // tile ahead): with ~2.5 tiles per resident workgroup a static stride would leave half the chip idle for the
-    // third round.  Direct mode (point lists) keeps the static stride.
-    int* ticket = src.counters ? const_cast<int*>(src.counters) + TF_TICKET_SLOT : nullptr;
-    int* tbox = reinterpret_cast<int*>(lds + L.offPre) + TF_N_SHARDS + 2;
-    if (ticket && tid0 == 0) tbox[0] = atomicAdd(ticket, 1);
-    __syncthreads();
-    for (int t = ticket ? tbox[0] : (int)blockIdx.x;; t = ticket ? tbox[0] : t + (int)gridDim.x) {
-        int s0, n;
-        if (!locate_tile(src, pre, t, s0, n)) break;
+    for (int v = v_begin;;) {
+        FChunk ck;
+        if (!fwd_locate(src, pre, v, v_end, ck)) break;
+        const int n = ck.n();
+        v += n;
         // thread coordinates from an opaque copy of the thread id, so that no per-thread address of a later phase is
-        // computed (and kept in registers) outside the tile loop: the kernel has 128 VGPRs at 4 waves per SIMD
+        // computed (and kept in registers) outside the chunk loop: the kernel has 128 VGPRs at 4 waves per SIMD
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        const int wave = tid >> 6, lane = tid & 63;
-        __syncthreads();                                   // everyone has read tbox[0]
-        // next tile: the returning atomic is issued now and its result parked in a register; it reaches the LDS box
-        // at the end of this tile, so thread 0 does not sit on the atomic's latency here
-        int t_next = 0;
-        if (ticket && tid == 0) t_next = atomicAdd(ticket, 1);
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        auto at = [&](int r) { return ck.at(r); };
         TF_MARK(7);
 
-        // ---- tile info
+        // ---- chunk info (requested during the previous chunk)
         if (tid < M) {
-            float x[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f};
-            if (tid < n) {
-                const size_t s = (size_t)s0 + tid;
-                x[0] = src.app_xyz[s * 3]; x[1] = src.app_xyz[s * 3 + 1]; x[2] = src.app_xyz[s * 3 + 2];
-                if (src.rays) {
-                    const int ray = src.app_ray[s];
-                    const float* rp = src.rays + (size_t)ray * 6 + 3;
-                    v[0] = rp[0]; v[1] = rp[1]; v[2] = rp[2];
-                    if (src.ndc) {   // viewdirs / rays_norm  (tensorBase.py:341-343)
-                        float q = v[0] * v[0];
-                        q = q + v[1] * v[1];
-                        q = q + v[2] * v[2];
-                        const float nrm = sqrtf(q);
-                        v[0] = v[0] / nrm; v[1] = v[1] / nrm; v[2] = v[2] / nrm;
-                    }
-                }
+            if (src.ndc && tid < n) {   // viewdirs / rays_norm  (tensorBase.py:341-343)
+                float q = nx_v[0] * nx_v[0];
+                q = q + nx_v[1] * nx_v[1];
+                q = q + nx_v[2] * nx_v[2];
+                const float nrm = sqrtf(q);
+                nx_v[0] = nx_v[0] / nrm; nx_v[1] = nx_v[1] / nrm; nx_v[2] = nx_v[2] / nrm;
             }
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                ixyz[tid * 3 + a] = x[a];
-                iview[tid * 3 + a] = v[a];
+                ixyz[tid * 3 + a] = nx_x[a];
+                iview[tid * 3 + a] = nx_v[a];
             }
         }
         __syncthreads();
+        {
+            FChunk c1;
+            if (fwd_locate(src, pre, v, v_end, c1)) fetch_info(c1, tid);
+        }
         TF_MARK(0);
 
         // ---- 1. appearance gather -> V: 8 lanes per sample
         {
-            const int smp = wave * 8 + (lane >> 3), sub = lane & 7;
+            const int smp = (tid >> 6) * 8 + (lane >> 3), sub = lane & 7;
             float u[3] = {ixyz[smp * 3], ixyz[smp * 3 + 1], ixyz[smp * 3 + 2]};
             float* vrow = regA + smp * L.sv;
             app_products(S, u, sub, vrow, 8);
@@ -122,18 +174,11 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
         TF_MARK(1);
         if (save.v) {     // training: the product rows go back to HBM for the backward (dB = dfeat^T V), 16 B per lane
             const int nat = S.n_app_total;
-            float* dst = save.v + (size_t)s0 * nat;
             if ((nat & 3) == 0) {
-                const int w4 = nat >> 2;
-                const float inv = 1.f / (float)w4;
-                for (int q = tid; q < n * w4; q += NT) {
-                    int row, c4;
-                    row_quad(q, w4, inv, row, c4);
-                    *reinterpret_cast<f32x4*>(dst + (size_t)q * 4) = *reinterpret_cast<const f32x4*>(regA + row * L.sv + 4 * c4);
-                }
+                save_rows<NT>(save.v, regA, L.sv, nat, n, tid, at);
             } else {
                 for (int smp = wave; smp < n; smp += NW)
-                    for (int c = lane; c < nat; c += 64) dst[(size_t)smp * nat + c] = regA[smp * L.sv + c];
+                    for (int c = lane; c < nat; c += 64) save.v[at(smp) * nat + c] = regA[smp * L.sv + c];
             }
         }
 
@@ -149,12 +194,11 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
                 const int f = 16 * bf + 4 * g + e;
                 if (f < S.app_dim) {
                     regB[smp * L.sx + f] = acc[0][0][e];
-                    if (feat_out && smp < n) feat_out[((size_t)s0 + smp) * S.app_dim + f] = acc[0][0][e];
+                    if (feat_out && smp < n) feat_out[at(smp) * S.app_dim + f] = acc[0][0][e];
                 }
             }
         }
         if (feat_out) {      // compute_appfeature hook: features only
-            if (ticket && tid == 0) tbox[0] = t_next;
             __syncthreads();
             continue;
         }
@@ -180,9 +224,8 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
                     for (int k = 0; k < 9; ++k) a += y[k] * x[ch * 9 + k];
                     o = fmaxf(a + 0.5f, 0.f);
                 }
-                rgb_out[((size_t)s0 + smp) * 3 + ch] = o;
+                rgb_out[at(smp) * 3 + ch] = o;
             }
-            if (ticket && tid == 0) tbox[0] = t_next;
             __syncthreads();
             continue;
         }
@@ -207,100 +250,120 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
                 if (c < kp) regB[smp * L.sx + c] = 0.f;
             }
         }
+        const int FC = S.feature_c, kp1 = kpad16(S.in_c), kt1 = kp1 / 16;
+        const int f_base = 16 * NFW * (wave % FG), s_base = 16 * NSW * (wave / FG);
+        const int lc = lane & 15, lg = lane >> 4;
+        f32x4 fr1[PRE ? KG1 : 1][1];          // layer-1 weight fragments, in flight across the barrier
+        if constexpr (PRE) load_a_frags<1, KG1>(S.w1, kp1, f_base, kt1, lane, fr1);
         __syncthreads();
         TF_MARK(3);
-        if (save.x) {     // training: the MLP input rows (zero padded to a multiple of 16) for the backward
-            const int w4 = kpad16(S.in_c) >> 2;
-            const float inv = 1.f / (float)w4;
-            float* dst = save.x + (size_t)s0 * (4 * w4);
-            for (int q = tid; q < n * w4; q += NT) {
-                int row, c4;
-                row_quad(q, w4, inv, row, c4);
-                *reinterpret_cast<f32x4*>(dst + (size_t)q * 4) = *reinterpret_cast<const f32x4*>(regB + row * L.sx + 4 * c4);
-            }
-        }
+        if (save.x) save_rows<NT>(save.x, regB, L.sx, kp1, n, tid, at);   // training: the (zero padded) MLP input rows
 
         // ---- 4. hidden layers
-        const int FC = S.feature_c;
-        const int f_base = 16 * NFW * (wave % FG), s_base = 16 * NSW * (wave / FG);
+        f32x4 fr2[PRE ? (FT <= 8 ? FT : 1) : 1][1];
         {
             f32x4 acc[NFW][NSW];
 #pragma unroll
             for (int i = 0; i < NFW; ++i)
 #pragma unroll
                 for (int j = 0; j < NSW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            mma_block<NFW, NSW>(S.w1, kpad16(S.in_c), f_base, regB, L.sx, s_base, kpad16(S.in_c) / 16, acc, lane);
-            const int c = lane & 15, g = lane >> 4;
+            if constexpr (PRE) {
+                mma_frags<1, NSW, KG1>(fr1, regB, L.sx, s_base, kt1, acc, lane);
+                load_a_frags<1, FT>(S.w2, kpad16(FC), f_base, FT, lane, fr2);     // layer 2's weights: behind this epilogue
+            } else {
+                mma_block<NFW, NSW>(S.w1, kp1, f_base, regB, L.sx, s_base, kt1, acc, lane);
+            }
 #pragma unroll
             for (int i = 0; i < NFW; ++i) {
-                const int f = f_base + 16 * i + 4 * g;
+                const int f = f_base + 16 * i + 4 * lg;
                 const f32x4 bias = *reinterpret_cast<const f32x4*>(S.b1 + f);
 #pragma unroll
                 for (int j = 0; j < NSW; ++j) {
                     f32x4 h = acc[i][j] + bias;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) h[e] = fmaxf(h[e], 0.f);
-                    *reinterpret_cast<f32x4*>(regA + (s_base + 16 * j + c) * L.sh + f) = h;
+                    *reinterpret_cast<f32x4*>(regA + (s_base + 16 * j + lc) * L.sh + f) = h;
                 }
             }
         }
         __syncthreads();
         TF_MARK(4);
-        if (save.h1) save_rows<NT>(save.h1 + (size_t)s0 * FC, regA, L.sh, FC, n, tid);
+        if (save.h1) save_rows<NT>(save.h1, regA, L.sh, FC, n, tid, at);
+        // output-layer weights as MFMA fragments (rows 0..2 of a 16-row operand tile, the other rows zero) for the waves
+        // that run the output layer (0..3)
+        constexpr int KG3 = FT <= 8 ? FT : 8;
+        f32x4 fr3[KG3];
         {
             f32x4 acc[NFW][NSW];
 #pragma unroll
             for (int i = 0; i < NFW; ++i)
 #pragma unroll
                 for (int j = 0; j < NSW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            mma_block<NFW, NSW>(S.w2, kpad16(FC), f_base, regA, L.sh, s_base, FC / 16, acc, lane);
-            const int c = lane & 15, g = lane >> 4;
+            if constexpr (PRE) mma_frags<1, NSW, FT>(fr2, regA, L.sh, s_base, FT, acc, lane);
+            else mma_block<NFW, NSW>(S.w2, kpad16(FC), f_base, regA, L.sh, s_base, FC / 16, acc, lane);
 #pragma unroll
             for (int i = 0; i < NFW; ++i) {
-                const int f = f_base + 16 * i + 4 * g;
+                const int f = f_base + 16 * i + 4 * lg;
                 const f32x4 bias = *reinterpret_cast<const f32x4*>(S.b2 + f);
 #pragma unroll
                 for (int j = 0; j < NSW; ++j) {
                     f32x4 h = acc[i][j] + bias;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) h[e] = fmaxf(h[e], 0.f);
-                    *reinterpret_cast<f32x4*>(regB + (s_base + 16 * j + c) * L.sh + f) = h;
+                    *reinterpret_cast<f32x4*>(regB + (s_base + 16 * j + lc) * L.sh + f) = h;
                 }
             }
         }
         __syncthreads();
         TF_MARK(5);
-        if (save.h2) save_rows<NT>(save.h2 + (size_t)s0 * FC, regB, L.sh, FC, n, tid);
-
-        // ---- 5. output layer + sigmoid: 8 lanes per sample
-        {
-            const int smp = tid >> 3, sub = tid & 7;
-            const float* h = regB + smp * L.sh;
-            float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-            for (int f = sub * 4; f < FC; f += 32) {
-                const f32x4 hv = *reinterpret_cast<const f32x4*>(h + f);
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(S.w3 + f);
-                const f32x4 w1 = *reinterpret_cast<const f32x4*>(S.w3 + FC + f);
-                const f32x4 w2 = *reinterpret_cast<const f32x4*>(S.w3 + 2 * FC + f);
+        if (save.h2) save_rows<NT>(save.h2, regB, L.sh, FC, n, tid, at);
+        if (wave < 4) {      // all at once (unconditional loads, rows >= 3 zeroed after)
+            const int r3 = lc < 3 ? lc : 2;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    o0 = fmaf(hv[e], w0[e], o0);
-                    o1 = fmaf(hv[e], w1[e], o1);
-                    o2 = fmaf(hv[e], w2[e], o2);
+            for (int k = 0; k < KG3; ++k) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(S.w3 + r3 * FC + 16 * k + 4 * lg);
+                fr3[k] = lc < 3 ? w : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- 5. output layer + sigmoid on the MFMA: o[c][s] = sum_f W3[c][f] H2[s][f], W3 as rows 0..2 of a 16-row
+        // operand tile; wave w < 4 takes sample tile w (the other waves go on to the next chunk's info phase — nothing
+        // they write there is read here)
+        if (wave < 4) {
+            const int r = lane & 15, kq = lane >> 4;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};      // two chains: no dependent-MFMA stalls
+            const float* xp = regB + (16 * wave + r) * L.sh + 4 * kq;
+#pragma unroll
+            for (int k = 0; k < KG3; ++k) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(xp + 16 * k);
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fr3[k][e], b[e], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fr3[k][e + 1], b[e + 1], acc1, 0, 0, 0);
                 }
             }
-            o0 = quad_sum(o0); o1 = quad_sum(o1); o2 = quad_sum(o2);
-            o0 += __shfl_xor(o0, 4, 64); o1 += __shfl_xor(o1, 4, 64); o2 += __shfl_xor(o2, 4, 64);
-            if (sub == 0 && smp < n) {
-                float* o = rgb_out + ((size_t)s0 + smp) * 3;
-                o[0] = 1.f / (1.f + expf(-(o0 + S.b3[0])));
-                o[1] = 1.f / (1.f + expf(-(o1 + S.b3[1])));
-                o[2] = 1.f / (1.f + expf(-(o2 + S.b3[2])));
+            for (int kg = KG3; kg < FC / 16; ++kg) {        // feature_c 256: the second half of the k-groups, streamed
+                const int r3 = r < 3 ? r : 2;
+                const f32x4 w = *reinterpret_cast<const f32x4*>(S.w3 + r3 * FC + 16 * kg + 4 * kq);
+                const f32x4 a = r < 3 ? w : (f32x4){0.f, 0.f, 0.f, 0.f};
+                const f32x4 b = *reinterpret_cast<const f32x4*>(xp + 16 * kg);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc0, 0, 0, 0);
+            }
+            const f32x4 acc = acc0 + acc1;
+            // D[c = 4 lg + reg][s = lc]: lanes 0..15 hold the three channels of sample 16 wave + lc
+            const int smp = 16 * wave + lc;
+            if (lg == 0 && smp < n) {
+                float* o = rgb_out + at(smp) * 3;
+                o[0] = 1.f / (1.f + expf(-(acc[0] + S.b3[0])));
+                o[1] = 1.f / (1.f + expf(-(acc[1] + S.b3[1])));
+                o[2] = 1.f / (1.f + expf(-(acc[2] + S.b3[2])));
             }
         }
-        if (ticket && tid == 0) tbox[0] = t_next;
-        __syncthreads();
         TF_MARK(6);
+        // no barrier: the next chunk's info phase writes ixyz / iview only and ends in a barrier before anything
+        // touches the H2 region again
     }
     TF_FLUSH();
 }

@@ -101,7 +101,9 @@ __device__ __forceinline__ void load_a_frags(const float* __restrict__ Wg, int l
     for (int kg = 0; kg < KG; ++kg)
 #pragma unroll
         for (int i = 0; i < NF; ++i)
-            a[kg][i] = kg < kgroups ? *reinterpret_cast<const f32x4*>(wp + (size_t)16 * i * ldw + 16 * kg) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            // (k-groups past the end re-read the last one: unconditional loads — a guarded load is a branch and a wait of
+            // its own; mma_frags never uses those fragments)
+            a[kg][i] = *reinterpret_cast<const f32x4*>(wp + (size_t)16 * i * ldw + 16 * (kg < kgroups ? kg : kgroups - 1));
     // keep the requests HERE: without the fence the scheduler sinks each load down to its first use and waits for it
     // there (s_waitcnt vmcnt(0) per fragment: eight serialized L2 round trips per phase)
     __builtin_amdgcn_sched_barrier(0);
