@@ -80,7 +80,8 @@ class TfBinJob(C.Structure):
                 ("slot", C.c_int), ("seg_cap", C.c_int), ("xyz", _fp), ("grad", _fp), ("grad_ld", C.c_int),
                 ("tile", C.c_int), ("bucket", C.c_int), ("chunk", C.c_int),
                 ("hist", _fp), ("offsets", _fp), ("cursor", _fp), ("chunk_off", _fp), ("binned", _fp),
-                ("nkeys", C.c_int), ("hist_zeroed", C.c_int), ("stage", C.c_int)]
+                ("nkeys", C.c_int), ("hist_zeroed", C.c_int), ("stage", C.c_int), ("binned_cap", C.c_int),
+                ("items_cap", C.c_int), ("status", _fp)]
 
 
 class TfCamera(C.Structure):
@@ -155,6 +156,7 @@ _SIGS = {
     "tf_bin_keys_per_entry": [C.c_int, C.POINTER(C.c_int * 3)],
     "tf_binned_scatter": [C.POINTER(TfBinJob), _fp],
     "tf_binned_sort_pair": [C.POINTER(TfBinJob), C.POINTER(TfBinJob), _fp],
+    "tf_bin_status": [_fp, C.POINTER(C.c_int), _fp],
     "tf_shade_backward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp,
                           C.POINTER(TfShadeGrads), _fp],
     "tf_adam_step": [C.POINTER(TfAdamJob), _fp],

@@ -64,6 +64,10 @@ def _bin_job(model, ws, part, factors, grid, stage, fgrads=None, grad=None, grad
     j.cursor, j.chunk_off = ints + 4 * (nmax + 8), ints + 8 * (nmax + 8)
     j.binned, j.nkeys = (ws.binned_app if app else ws.binned).data_ptr(), nkeys
     j.stage = stage
+    # capacities the kernels check every position against (TfBinJob.status collects violations)
+    j.binned_cap = ws.binned_len
+    j.items_cap = ws.bin_ints_len - (2 * (nmax + 8) + nkeys + 1)      # ints behind chunk_off[nkeys + 1]
+    j.status = ws.bin_status.data_ptr()
     return j
 
 

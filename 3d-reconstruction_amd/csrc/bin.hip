@@ -109,6 +109,10 @@ __global__ __launch_bounds__(256) void zero_ints_kernel(int* __restrict__ p, int
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
 }
 
+__device__ __forceinline__ void flag(const TfBinJob& J, int bit) {
+    if (J.status) atomicOr(J.status, bit);
+}
+
 constexpr int kKeyRange = 16384;   // keys per LDS pass of the count / scan / fill kernels (64 KB of ints)
 
 // entries of shard g handled by slice k: local = k*256 + tid, += kSlices*256.  Jobs with more than kKeyRange keys
@@ -216,7 +220,10 @@ __global__ __launch_bounds__(1024, 8) void bin_scan_kernel(const SortArgs A) {
             const int h = sh[i];
             sh[i] = run;
             const int nc = (h + cm1) >> csh;
-            for (int c = 0; c < nc; ++c) items[run2 + c] = k0 + i;
+            for (int c = 0; c < nc; ++c) {
+                if (run2 + c < J.items_cap) items[run2 + c] = k0 + i;
+                else flag(J, TF_BIN_ERR_ITEMS);
+            }
             run += h;
             run2 += nc;
         }
@@ -282,8 +289,11 @@ __global__ __launch_bounds__(kSortThreads) void bin_fill_kernel(const SortArgs A
             sample_geom(J.grid, u, sg);
             int keys[6];
             sample_keys(K, J.grid, sg, keys);
-            TF_FOR_EACH_KEY(K, keys, key,
-                            if ((unsigned)(key - k0) < (unsigned)kn) J.binned[atomicAdd(&lh[key - k0], 1)] = (int)e);
+            TF_FOR_EACH_KEY(K, keys, key, if ((unsigned)(key - k0) < (unsigned)kn) {
+                const int pos = atomicAdd(&lh[key - k0], 1);
+                if ((unsigned)pos < (unsigned)J.binned_cap) J.binned[pos] = (int)e;
+                else flag(J, TF_BIN_ERR_BINNED);
+            });
         }
         __syncthreads();
     }
@@ -315,7 +325,12 @@ __host__ __device__ inline int lane_group(int c) { return c <= 16 ? 16 : (c <= 3
 __global__ __launch_bounds__(256, 4) void bin_scatter_kernel(const TfBinJob J, const KeyMap K, int ER, int cmax) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wstride = ER * (cmax + 8);
-    const int total = J.chunk_off[K.nkeys];
+    int total = J.chunk_off[K.nkeys];
+    if (total > J.items_cap) {          // never walk past the item table (a histogram that does not match the entries)
+        total = J.items_cap;
+        if (threadIdx.x == 0 && blockIdx.x == 0) flag(J, TF_BIN_ERR_ITEMS);
+    }
+    const int entry_cap = TF_N_SHARDS * J.seg_cap;
     const size_t rep = (size_t)(blockIdx.x % J.grads.n_rep) * J.grads.rep_stride;
     TF_T0();
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
@@ -328,8 +343,18 @@ __global__ __launch_bounds__(256, 4) void bin_scatter_kernel(const TfBinJob J, c
         float* pre = smem + wave * wstride;            // [ER][C]
         float* meta = pre + ER * cmax;                 // [ER][8]: cell (int), w00, w01, w10, w11 | cell, w0, w1
         float* blk0 = smem + 4 * wstride;              // 4 private accumulation blocks (one per wave)
-        const int key = J.chunk_off[K.nkeys + 1 + w], chunk = w - J.chunk_off[key];
-        const int beg = J.offsets[key] + chunk * J.chunk, end = min(J.offsets[key + 1], beg + J.chunk);
+        const int key = J.chunk_off[K.nkeys + 1 + w];
+        if ((unsigned)key >= (unsigned)K.nkeys) {       // not a key: an item slot the scan never wrote
+            if (threadIdx.x == 0) flag(J, TF_BIN_ERR_ITEMS);
+            continue;
+        }
+        const int chunk = w - J.chunk_off[key];
+        int beg = J.offsets[key] + chunk * J.chunk, end = min(J.offsets[key + 1], beg + J.chunk);
+        if (beg < 0 || end > J.binned_cap) {      // (ranges outside binned[] are dropped and reported)
+            if (threadIdx.x == 0) flag(J, TF_BIN_ERR_BINNED);
+            beg = max(beg, 0);
+            end = min(end, J.binned_cap);
+        }
         const bool is_line = key >= K.line_base[0];
         int i = 0, local = 0, cg = 0;
         if (is_line) {
@@ -365,7 +390,12 @@ __global__ __launch_bounds__(256, 4) void bin_scatter_kernel(const TfBinJob J, c
         const int LPE = 64 / ER, ent = lane / LPE, sub = lane - ent * LPE;
         auto idx_of = [&](int rd) {
             const int b = beg + (rd * 4 + wave) * ER + ent;
-            return (rd < rounds && b < end) ? J.binned[b] : -1;
+            int e = (rd < rounds && b < end) ? J.binned[b] : -1;
+            if (e >= entry_cap) {       // not an entry of this list: skip it, keep the evidence
+                flag(J, TF_BIN_ERR_ENTRY);
+                e = -1;
+            }
+            return e;
         };
         int e_cur = idx_of(0), e_nxt = idx_of(1);
         float u_cur[3] = {0.f, 0.f, 0.f};
@@ -383,7 +413,15 @@ __global__ __launch_bounds__(256, 4) void bin_scatter_kernel(const TfBinJob J, c
             __syncthreads();                         // blk zeroed / previous round's staging consumed
             TF_MARK(1);
             // ---------------- stage: LPE = 64 / ER lanes per entry, lane `sub` takes channel quads sub, sub+LPE, ...
-            if (ent < nk) {
+            if (ent < nk && e_cur < 0) {     // a rejected entry contributes nothing
+                if (sub == 0) {
+                    float* mrow = meta + ent * 8;
+                    reinterpret_cast<int*>(mrow)[0] = 0;
+                    mrow[1] = mrow[2] = mrow[3] = mrow[4] = 0.f;
+                }
+                for (int c = sub; c < C; c += LPE) pre[ent * C + c] = 0.f;
+            }
+            if (ent < nk && e_cur >= 0) {
                 const int e = e_cur;
                 const float u[3] = {u_cur[0], u_cur[1], u_cur[2]};
                 const Tap2 tp = make_tap2(u[mat0(i)], u[mat1(i)], W, Hh);
@@ -504,6 +542,17 @@ int tf_debug_phase_cycles_bin(unsigned long long* out16, int reset) {
     return (int)e;
 }
 #endif
+
+int tf_bin_status(const int* status, int* bits_out, tf_stream_t stream) {
+    int bits = 0;
+    if (status) {
+        hipError_t e = hipMemcpyAsync(&bits, status, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (bits_out) *bits_out = bits;
+    return bits ? (int)hipErrorAssert : 0;
+}
 
 int tf_bin_nkeys(int model, const int grid[3], const int n_comp[3], int tile, int bucket) {
     return make_keymap(grid, n_comp, tile, bucket, model == TF_MODEL_CP).nkeys;

@@ -180,7 +180,8 @@ class _Workspace:
                 nkeys, kpe = max(binned[0], binned[1]), binned[2]
                 n_ints = 4 * (nkeys + 8) + kpe * cap // 256 + 64
                 # one sort workspace per job (density, appearance): both sorts run early, next to the shading kernels
-                spec += [("ent_xyz", cap * 3, torch.float32), ("ent_df", cap, torch.float32), ("ent_offset", R, torch.int32),
+                spec += [("bin_status", 64, torch.int32),
+                         ("ent_xyz", cap * 3, torch.float32), ("ent_df", cap, torch.float32), ("ent_offset", R, torch.int32),
                          ("binned", kpe * cap, torch.int32), ("bin_ints", n_ints, torch.int32),
                          ("binned_app", kpe * cap, torch.int32), ("bin_ints_app", n_ints, torch.int32)]
         if debug:
@@ -197,6 +198,9 @@ class _Workspace:
         self.hist_app = self.zero_block[n_ctr + n_hist[0]:]
         self.R, self.N, self.seg_cap, self.cap, self.words = R, N, seg_cap, cap, words
         self.save_valid, self.debug, self.binned_cfg = save_valid, debug, binned
+        if hasattr(self, "bin_status"):
+            self.bin_status.zero_()        # sticky error word of the binned scatter (TfBinJob.status)
+            self.bin_ints_len, self.binned_len = self.bin_ints.numel(), self.binned.numel()
         self.busy = False
         self.owner = None      # weakref to the autograd ctx that holds this (training) workspace until its backward
         self.counters2d = self.counters.view(H.N_SHARDS, H.SHARD_STRIDE)
@@ -703,6 +707,20 @@ class TensorBase(nn.Module):
         # caller gets the first shard's counter view instead (undefined value, no launch)
         num_valid = ctx['n_shaded'] if ctx['n_shaded'] is not None else ctx['ws'].counters2d[0, 0]
         return ctx['rgb_map'], ctx['depth'], num_valid
+
+    def check_scatter_status(self):
+        """Raises if a binned-scatter kernel of this model's training workspaces ever refused an out-of-range position
+        (TfBinJob.status; one small D2H copy and a stream sync per workspace: call it at logging points, not per step)."""
+        for pool in self._train_ws.values():
+            for ws in pool:
+                if ws.binned_cfg is None:
+                    continue
+                bits = C.c_int(0)
+                rc = H.lib().tf_bin_status(ws.bin_status.data_ptr(), C.byref(bits), _stream())
+                if rc != 0:
+                    raise H.HipError(f"tf_binned_scatter refused out-of-range positions (status bits {bits.value}: 1 = sorted "
+                                     f"position outside binned[], 2 = work-item table overflow, 4 = entry index outside "
+                                     f"the list): the key histogram did not describe the entries")
 
     # ---- public feature hooks (used by compute_alpha in the reference) --------------------------
     def compute_densityfeature(self, xyz_sampled, mask=None):

@@ -316,7 +316,18 @@ typedef struct TfBinJob {
     int stage;                /* 0: sort the entries by key, then scatter; 1: sort only (needs xyz and the counters, not
                                * grad: can run as soon as the entry coordinates exist, on another stream); 2: scatter
                                * only, the workspace holds the result of an earlier stage-1 call of the same job */
+    int binned_cap;           /* ints in binned[]; */
+    int items_cap;            /* ints in the work-item table behind chunk_off[nkeys + 1] */
+    int* status;              /* device word (sticky, may be NULL): the kernels OR a TF_BIN_ERR_* bit into it instead of
+                               * writing / reading outside binned[], the item table or the entry list — a histogram that
+                               * does not describe the entries (e.g. not zeroed) then costs a wrong gradient and this
+                               * flag, never a wild access.  Read it with tf_bin_status. */
 } TfBinJob;
+#define TF_BIN_ERR_BINNED 1   /* a sorted position fell outside binned[] */
+#define TF_BIN_ERR_ITEMS 2    /* the work-item table would overflow */
+#define TF_BIN_ERR_ENTRY 4    /* binned[] held an entry index outside the entry list */
+/* Copies *status to the host (synchronises the stream): 0, or hipErrorAssert (710) with the bits in *bits_out. */
+int tf_bin_status(const int* status, int* bits_out, tf_stream_t stream);
 #define TF_BIN_MAX_KEYS 262144  /* tf_binned_scatter returns hipErrorInvalidValue above this (the sort walks the keys in
                                  * LDS-sized ranges of 16384; ~1000^3 grids at 48 components stay below) */
 /* Decompositions wider than 16 components are split into 16-component groups, each with its own key, so the

@@ -303,3 +303,33 @@ def test_graphed_step_with_random_background(recon):
         finals.append({k: v.detach().clone() for k, v in model.state_dict().items()})
     assert len(set(round(v, 4) for v in losses[0])) > 2          # the two backgrounds give visibly different losses
     _same_trajectory(finals, init, losses)
+
+
+@pytest.mark.gpu
+def test_binned_scatter_refuses_positions_outside_its_buffers(recon):
+    """Round-1 faults came from a key histogram that was not zeroed before a graph replay: the fill kernel then wrote
+    through offsets beyond `binned[]`.  The kernels now check every position against the buffer sizes in TfBinJob and
+    report through the sticky status word (tf_bin_status) instead: poison the histogram, run a backward, expect the
+    error — and no memory fault."""
+    import ctypes as C
+    from recon_amd import synthetic as S
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    aabb = torch.tensor(S.LEGO_AABB, device=dev)
+    model = recon.TensorVMSplit(S.lego_args(density_n_comp=(8, 8, 8), app_n_comp=(16, 16, 16)), aabb, [32] * 3,
+                                S.LEGO_NEAR_FAR, dev)
+    S.make_trained_like(model, recon.AlphaGridMask, mask_res=32, radius=0.7)
+    rays = S.blender_rays(1)[:2048].to(dev).contiguous()
+    rgb, _, _ = model(rays, None, white_bg=True, is_train=True, N_samples=100)
+    rgb.sum().backward()
+    model.check_scatter_status()                       # a clean step raises nothing
+    ws = model.last["ws"]
+    model.zero_grad()
+    rgb, _, _ = model(rays, None, white_bg=True, is_train=True, N_samples=100)
+    ws = model.last["ws"]
+    ws.hist_app.fill_(1 << 20)                         # what a skipped zero-fill leaves behind, exaggerated
+    ws.hist_density.fill_(1 << 20)
+    rgb.sum().backward()
+    torch.cuda.synchronize()
+    with pytest.raises(recon._hip.HipError, match="refused out-of-range"):
+        model.check_scatter_status()
