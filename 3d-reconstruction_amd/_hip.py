@@ -50,7 +50,7 @@ class TfMarchIO(C.Structure):
                 ("acc", _fp), ("depth", _fp), ("app_offset", _fp), ("app_count", _fp), ("val_count", _fp),
                 ("counters", _fp), ("app_ray", _fp), ("app_xyz", _fp), ("app_w", _fp),
                 ("val_idx", _fp), ("val_feat", _fp), ("dbg_bbox_bits", _fp), ("dbg_valid_bits", _fp),
-                ("dbg_app_bits", _fp), ("ent_xyz", _fp), ("ent_offset", _fp)]
+                ("dbg_app_bits", _fp), ("ent_xyz", _fp), ("ent_offset", _fp), ("dbg_z", _fp)]
 
 
 class TfPeBlock(C.Structure):
@@ -143,6 +143,7 @@ _SIGS = {
     "tf_composite_forward": [C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp, _fp, _fp],
     "tf_density_points": [C.POINTER(TfField), _fp, C.c_int, _fp, _fp],
     "tf_appfeature_points": [C.POINTER(TfShade), _fp, C.c_int, _fp, _fp],
+    "tf_shade_points": [C.POINTER(TfShade), _fp, _fp, _fp, C.c_int, _fp, _fp],
     "tf_alpha_points": [C.POINTER(TfField), _fp, C.c_int, C.c_float, _fp, _fp],
     "tf_sample_alpha_points": [_fp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3), _fp,
                                C.c_int, _fp, _fp],

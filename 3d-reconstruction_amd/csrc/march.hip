@@ -62,11 +62,34 @@ __global__ __launch_bounds__(64) void march_forward_kernel(const TfField F, cons
     const int words = (N + 63) >> 6;
 
     // ---------------- phase A: validity + compaction
+    // Samples behind the ray's exit from the box cannot be valid (tensorBase.py:206): the walk stops two steps past the
+    // slab exit (two steps of slack >> the rounding of p = o + d z against the slab arithmetic; axes with d == 0 never
+    // exit).  At config 2 that is 569 of 1039 slots.  NDC rays keep the full walk (their table spans near..far).
+    int n_walk = N;
+    if (!io.ndc) {
+        float t_exit = INFINITY;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (ray.d[a] != 0.f) {
+                const float ta = (F.aabb_hi[a] - ray.o[a]) / ray.d[a], tb = (F.aabb_lo[a] - ray.o[a]) / ray.d[a];
+                t_exit = fminf(t_exit, fmaxf(ta, tb));
+            }
+        }
+        const float span = (t_exit - ray.tmin) / F.step;            // NaN / inf -> full walk
+        if (span < (float)N) n_walk = span > 0.f ? min(N, (int)span + 3) : min(N, 3);
+    }
+    if (io.dbg_z)          // tests: the sample positions along the ray, bit for bit (tensorBase.py:198-203)
+        for (int i = lane; i < N; i += 64) io.dbg_z[(size_t)r * N + i] = sample_z(F, ray, ztab, i);
+    if (lane == 0 && (io.dbg_bbox_bits || io.dbg_valid_bits))
+        for (int wd = (n_walk + 63) >> 6; wd < words; ++wd) {        // words the shortened walk does not reach
+            if (io.dbg_bbox_bits) io.dbg_bbox_bits[(size_t)r * words + wd] = 0;
+            if (io.dbg_valid_bits) io.dbg_valid_bits[(size_t)r * words + wd] = 0;
+        }
     int cnt = 0, nbbox = 0;
-    for (int base = 0; base < N; base += 64) {
+    for (int base = 0; base < n_walk; base += 64) {
         const int i = base + lane;
         bool inb = false, val = false;
-        if (i < N) {
+        if (i < n_walk) {
             float z = sample_z(F, ray, ztab, i);
             float p[3];
             sample_pos(ray, z, p);

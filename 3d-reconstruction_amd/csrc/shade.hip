@@ -118,6 +118,8 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
             if (src.rays) {
                 const float* rp = src.rays + (size_t)src.app_ray[s] * 6 + 3;
                 nx_v[0] = rp[0]; nx_v[1] = rp[1]; nx_v[2] = rp[2];
+            } else if (src.view_direct) {
+                nx_v[0] = src.view_direct[s * 3]; nx_v[1] = src.view_direct[s * 3 + 1]; nx_v[2] = src.view_direct[s * 3 + 2];
             }
         }
     };
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
         TF_MARK(0);
 
         // ---- 1. appearance gather -> V: 8 lanes per sample
-        {
+        if (!src.feat_in) {
             const int smp = (tid >> 6) * 8 + (lane >> 3), sub = lane & 7;
             float u[3] = {ixyz[smp * 3], ixyz[smp * 3 + 1], ixyz[smp * 3 + 2]};
             float* vrow = regA + smp * L.sv;
@@ -183,7 +185,13 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
         }
 
         // ---- 2. basis: feat[s][f] = sum_k B[f][k] V[s][k]; (feature tile, sample tile) pairs dealt to the 8 waves
-        for (int pr = wave; pr < 4 * NB; pr += NW) {
+        if (src.feat_in) {      // renderModule(pts, viewdirs, features) alone: the caller's features are the MLP input
+            for (int it = tid; it < M * S.app_dim; it += NT) {
+                const int smp = it / S.app_dim, d = it - smp * S.app_dim;
+                regB[smp * L.sx + d] = smp < n ? src.feat_in[at(smp) * S.app_dim + d] : 0.f;
+            }
+        }
+        for (int pr = src.feat_in ? 4 * NB : wave; pr < 4 * NB; pr += NW) {
             const int bf = pr >> 2, bs = pr & 3;
             f32x4 acc[1][1];
             acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -412,7 +420,7 @@ extern "C" {
 int tf_shade_forward(const TfShade* shade, const float* rays, int ndc, const int* counters, int seg_cap,
                      const int* app_ray, const float* app_xyz, float* rgb_out, int max_workgroups,
                      const TfShadeSave* save, tf_stream_t stream) {
-    TileSrc src{counters, seg_cap, 0, app_ray, app_xyz, rays, ndc};
+    TileSrc src{counters, seg_cap, 0, app_ray, app_xyz, rays, ndc, nullptr, nullptr};
     const int wgs = max_workgroups > 0 && max_workgroups < 512 ? max_workgroups : 512;
     if (save && shade->head != TF_HEAD_MLP && save->x) return (int)hipErrorInvalidValue;   // X rows exist for MLP heads only
     return launch_shade(shade, src, rgb_out, nullptr, wgs, (hipStream_t)stream, save ? *save : TfShadeSave{nullptr, nullptr, nullptr, nullptr});
@@ -420,10 +428,20 @@ int tf_shade_forward(const TfShade* shade, const float* rays, int ndc, const int
 
 int tf_appfeature_points(const TfShade* shade, const float* xyz_n, int n, float* out_feat, tf_stream_t stream) {
     if (n <= 0) return 0;
-    TileSrc src{nullptr, 0, n, nullptr, xyz_n, nullptr, 0};
+    TileSrc src{nullptr, 0, n, nullptr, xyz_n, nullptr, 0, nullptr, nullptr};
     int blocks = (n + M - 1) / M;
     if (blocks > 512) blocks = 512;
     return launch_shade(shade, src, nullptr, out_feat, blocks, (hipStream_t)stream);
+}
+
+int tf_shade_points(const TfShade* shade, const float* pts_n, const float* viewdirs, const float* features, int n,
+                    float* rgb_out, tf_stream_t stream) {
+    if (n <= 0) return 0;
+    if (!pts_n || !viewdirs || !features || !rgb_out) return (int)hipErrorInvalidValue;
+    TileSrc src{nullptr, 0, n, nullptr, pts_n, nullptr, 0, viewdirs, features};
+    int blocks = (n + M - 1) / M;
+    if (blocks > 512) blocks = 512;
+    return launch_shade(shade, src, rgb_out, nullptr, blocks, (hipStream_t)stream);
 }
 
 #ifdef TF_PHASE_TIMING

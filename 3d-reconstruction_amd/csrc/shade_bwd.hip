@@ -810,7 +810,7 @@ int tf_shade_backward(const TfShade* shade, const float* rays, int ndc, const in
     if (e != hipSuccess) return (int)e;
     if (!grads->dv_out || !grads->wslab || !grads->x_saved || !grads->rgb_fwd || !shade->w1t || !shade->w2t)
         return (int)hipErrorInvalidValue;
-    TileSrc src{counters, seg_cap, 0, app_ray, app_xyz, rays, ndc};
+    TileSrc src{counters, seg_cap, 0, app_ray, app_xyz, rays, ndc, nullptr, nullptr};
 #ifdef TF_PHASE_TIMING
     const int n_wg = g_dbg_bwd_wgs;
 #else

@@ -301,6 +301,8 @@ struct TileSrc {          // where a tile's samples come from
     const float* app_xyz;
     const float* rays;
     int ndc;
+    const float* view_direct;   // direct mode: (n,3) per-sample view directions instead of rays[app_ray[s]]
+    const float* feat_in;       // direct mode: (n, app_dim) appearance features given by the caller (renderModule alone)
 };
 
 // Enumerates the tiles of all shards: returns false when t is past the last tile.

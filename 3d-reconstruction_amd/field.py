@@ -126,9 +126,30 @@ class _MLPBase(nn.Module):
         self.mlp = nn.Sequential(l1, nn.ReLU(inplace=True), l2, nn.ReLU(inplace=True), l3)
         nn.init.constant_(self.mlp[-1].bias, 0)
 
+    _owner = None      # weakref to the field model that owns this head (set by TensorBase.init_render_func)
+
+    @torch.no_grad()
     def forward(self, pts, viewdirs, features, mask):
-        raise H.HipError("the shading MLP runs fused inside TensorBase.forward (csrc/shade.hip); "
-                         "call the field model, not renderModule, on this build")
+        """models/mlp.py:41-69 / :84-107 / :126-155 as a stand-alone call: rgb (S,3) of explicit (pts, viewdirs,
+        features) lists with the encoding masks `mask['pos' / 'view' / 'fea']` (or None) — tf_shade_points, the same
+        kernel that shades inside TensorBase.forward.  Inference only (training goes through the field model)."""
+        owner = self._owner() if self._owner is not None else None
+        if owner is None:
+            raise H.HipError("this shading head is not attached to a field model (TensorBase.init_render_func)")
+        dev = features.device
+        if not features.is_cuda:
+            raise H.HipError("renderModule needs its inputs on the GPU (no CPU path in this build)")
+        if owner._geom is None:
+            owner._field_desc([None, None, None])
+        shade, keep = owner._shade_desc([None, None, None], mask, dev)
+        n = features.shape[0]
+        f = features.detach().reshape(n, -1).to(torch.float32).contiguous()
+        p = pts.detach().reshape(n, 3).to(torch.float32).contiguous()
+        v = viewdirs.detach().reshape(n, 3).to(torch.float32).contiguous()
+        out = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        H.check(H.lib().tf_shade_points(C.byref(shade), p.data_ptr(), v.data_ptr(), f.data_ptr(), n, out.data_ptr(),
+                                        _stream()), "tf_shade_points")
+        return out
 
 
 class MLPRender_Fea(_MLPBase):
@@ -186,7 +207,7 @@ class _Workspace:
                          ("binned_app", kpe * cap, torch.int32), ("bin_ints_app", n_ints, torch.int32)]
         if debug:
             spec += [("dbg_bbox", R * words * 2, torch.int32), ("dbg_valid", R * words * 2, torch.int32),
-                     ("dbg_app", R * words * 2, torch.int32)]
+                     ("dbg_app", R * words * 2, torch.int32), ("dbg_z", R * N, torch.float32)]
         total = sum(((n * 4 + 255) // 256) * 256 for _, n, _ in spec)
         self.buf = torch.empty(total, dtype=torch.uint8, device=device)
         off = 0
@@ -282,6 +303,9 @@ class TensorBase(nn.Module):
             self.renderModule = shadingMode
         else:
             raise ValueError(f"Unrecognized shading module {shadingMode!r}")
+        if isinstance(self.renderModule, nn.Module):
+            import weakref
+            object.__setattr__(self.renderModule, "_owner", weakref.ref(self))
 
     def update_stepSize(self, gridSize):
         """models/tensorBase.py:104-116 (same fp32 torch arithmetic -> same stepSize / nSamples)."""
@@ -677,6 +701,7 @@ class TensorBase(nn.Module):
             ws.dbg_app.zero_()
             io.dbg_bbox_bits, io.dbg_valid_bits = ws.dbg_bbox.data_ptr(), ws.dbg_valid.data_ptr()
             io.dbg_app_bits = ws.dbg_app.data_ptr()
+            io.dbg_z = ws.dbg_z.data_ptr()
         self._timed("tf_march_forward", lib.tf_march_forward, C.byref(field), C.byref(io), st)
         sorted_on = after_march(ws, field, shade) if early else None
         save = None

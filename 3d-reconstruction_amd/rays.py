@@ -3,9 +3,8 @@
 
 `generate_rays(H, W, focal, c2w, ...)` returns the (n, 6) fp32 rays `[o, d]` of the requested pixels on the GPU,
 computed by `tf_generate_rays` with the arithmetic of `get_ray_directions[_blender]` + `get_rays`
-(+ `ndc_rays_blender`).  Parity note: `dataLoader/ray_utils.py` needs `kornia` and cannot be imported in the build
-container, so this function is checked against the torch restatement of those formulas in `synthetic.py`
-(parity unpinned against the reference itself)."""
+(+ `ndc_rays_blender`).  Pinned by tests/golden/aux_refs.npz: rays the reference's own `get_rays` /
+`ndc_rays_blender` produced (the module's `kornia` import is stubbed in the generator; neither function uses it)."""
 import ctypes as C
 
 import torch

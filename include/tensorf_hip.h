@@ -116,6 +116,7 @@ typedef struct TfMarchIO {
      * dL/df at ent_offset[r] + k. */
     float* ent_xyz;        /* (cap,3) or NULL */
     int* ent_offset;       /* (R) first density entry of the ray */
+    float* dbg_z;          /* tests (optional): (R, n_samples) the sample positions z of tensorBase.py:198-203 / :181-183 */
 } TfMarchIO;
 
 /* One positional-encoding block of the MLP input (mlp.py:8-13, 41-66, 84-103, 126-153). */
@@ -213,6 +214,12 @@ int tf_composite_forward(int n_rays, const int* app_offset, const int* app_count
  * the public hooks used by compute_alpha (tensorBase.py:298-318): out_f (S) / out_feat (S, app_dim). */
 int tf_density_points(const TfField* field, const float* xyz_n, int n, float* out_f, tf_stream_t stream);
 int tf_appfeature_points(const TfShade* shade, const float* xyz_n, int n, float* out_feat, tf_stream_t stream);
+/* renderModule(pts, viewdirs, features, mask) on explicit lists — the shading heads as stand-alone calls
+ * (MLPRender_Fea / MLPRender_PE / MLPRender mlp.py:41-69, 84-107, 126-155; SHRender / RGBRender :15-25): pts_n (n,3)
+ * normalised points (only the heads with a position encoding read them), viewdirs (n,3), features (n, app_dim);
+ * rgb_out (n,3).  The encoding masks are the TfPeBlock masks of `shade`. */
+int tf_shade_points(const TfShade* shade, const float* pts_n, const float* viewdirs, const float* features, int n,
+                    float* rgb_out, tf_stream_t stream);
 
 /* Backward of compositing + density: consumes d(loss)/d(rgb_map), the saved valid lists and
  * the per-sample rgb; produces d(loss)/d(rgb sample) for the shading backward and scatter-adds the

@@ -362,5 +362,66 @@ def main():
     print("free_mask done", {k: rec[k].shape for k in rec if k.startswith("0/")})
 
 
+def aux_refs():
+    """10: reference functions next to the path that round 1 only checked against restatements:
+      * loss.TVLoss (loss.py:120-141) on factor planes,
+      * dataLoader/ray_utils.get_rays (:66-87) and ndc_rays_blender (:90-107).
+    loss.py imports scipy / tqdm (present) and `utils` (stubbed as above); ray_utils.py imports
+    `kornia.create_meshgrid` at module level — a name only get_ray_directions[_blender] call, neither of which is
+    used here: the import is satisfied with a stub module whose attribute is never called.  The pixel directions fed
+    to get_rays are built with the formula of ray_utils.py:36-40 / :58-61 (meshgrid + 0.5), i.e. they are INPUTS of
+    this fixture, not reference outputs."""
+    for name in ("cv2", "torchvision", "torchvision.transforms", "plyfile", "skimage", "skimage.measure"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["cv2"].COLORMAP_JET = 2
+    k = types.ModuleType("kornia")
+    k.create_meshgrid = None            # never called by get_rays / ndc_rays_blender
+    sys.modules.setdefault("kornia", k)
+    import loss as ref_loss
+    from dataLoader import ray_utils as ref_rays
+    rec = {}
+    g = torch.Generator().manual_seed(2024)
+    tv = ref_loss.TVLoss()
+    for tag, shape in (("a", (1, 16, 40, 36)), ("b", (1, 48, 23, 31)), ("c", (1, 4, 7, 5))):
+        x = torch.randn(shape, generator=g).requires_grad_(True)
+        y = tv(x)
+        y.backward()
+        rec[f"tv/{tag}/x"] = x.detach().numpy()
+        rec[f"tv/{tag}/loss"] = np.float32(y.item())
+        rec[f"tv/{tag}/grad"] = x.grad.numpy()
+    # cameras: a Blender-style pose (OpenGL axes, blender.py:31,79) and an LLFF-style one
+    def pose(seed):
+        gg = torch.Generator().manual_seed(seed)
+        a = torch.randn(3, 3, generator=gg)
+        q, _ = torch.linalg.qr(a)
+        t = torch.randn(3, generator=gg) * 2
+        return torch.cat([q, t[:, None]], 1)
+    for tag, (H, W, focal, opengl, seed) in (("blender", (20, 24, 27.5, False, 1)), ("llff", (18, 26, 31.0, True, 2))):
+        j, i = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+        i, j = i + 0.5, j + 0.5
+        if opengl:   # get_ray_directions_blender, ray_utils.py:58-61
+            dirs = torch.stack([(i - W / 2) / focal, -(j - H / 2) / focal, -torch.ones_like(i)], -1)
+        else:        # get_ray_directions, ray_utils.py:36-40
+            dirs = torch.stack([(i - W / 2) / focal, (j - H / 2) / focal, torch.ones_like(i)], -1)
+        c2w = pose(seed)
+        ro, rd = ref_rays.get_rays(dirs, c2w)
+        rec[f"rays/{tag}/H"], rec[f"rays/{tag}/W"], rec[f"rays/{tag}/focal"] = np.int64(H), np.int64(W), np.float32(focal)
+        rec[f"rays/{tag}/opengl"] = np.int64(opengl)
+        rec[f"rays/{tag}/c2w"] = c2w.numpy()
+        rec[f"rays/{tag}/directions"] = dirs.numpy()
+        rec[f"rays/{tag}/rays_o"] = ro.numpy()
+        rec[f"rays/{tag}/rays_d"] = rd.numpy()
+        if opengl:   # llff.py:203: ndc_rays_blender(H, W, focal, 1.0, rays_o, rays_d)
+            no, nd = ref_rays.ndc_rays_blender(H, W, focal, 1.0, ro, rd)
+            rec[f"rays/{tag}/ndc_o"] = no.numpy()
+            rec[f"rays/{tag}/ndc_d"] = nd.numpy()
+    np.savez_compressed(os.path.join(OUT, "aux_refs.npz"), **rec)
+    print("aux_refs done:", sorted(k for k in rec if k.endswith("loss")), {k: rec[k].shape for k in rec if k.endswith("rays_d")})
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "aux":
+        aux_refs()
+    else:
+        main()
+        aux_refs()

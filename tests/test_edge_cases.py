@@ -89,8 +89,8 @@ def test_training_step_without_shaded_samples(recon):
 
 
 def test_generated_rays_match_the_loader_formulas(recon):
-    """tf_generate_rays against the torch expressions of dataLoader/ray_utils.py (restated here: the module itself
-    needs kornia and cannot be imported, so this row's parity is unpinned against the reference's own output)."""
+    """tf_generate_rays against the torch expressions of dataLoader/ray_utils.py restated here (more shapes and options
+    than the reference-generated fixture of test_generated_rays_match_the_reference_fixture covers)."""
     from recon_amd import synthetic as S
     H_, W_, f = 37, 53, 61.5
     g = torch.Generator().manual_seed(2)
@@ -118,6 +118,25 @@ def test_generated_rays_match_the_loader_formulas(recon):
     got = out.cpu()
     np.testing.assert_allclose(got[:, [0, 2, 3, 5]].numpy(), ref2[:, [0, 2, 3, 5]].numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(got[:, [1, 4]].numpy(), 1.1 * ref2[:, [1, 4]].numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_generated_rays_match_the_reference_fixture(recon):
+    """tf_generate_rays against rays the reference's own get_rays / ndc_rays_blender produced (dataLoader/ray_utils.py:
+    66-107; tests/golden/aux_refs.npz: gen_golden.py imports the module with a stub for the kornia import, which those
+    two functions never touch).  The camera-space pixel directions are the fixture's inputs."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "aux_refs.npz"))
+    for tag in ("blender", "llff"):
+        H_, W_, f = int(z[f"rays/{tag}/H"]), int(z[f"rays/{tag}/W"]), float(z[f"rays/{tag}/focal"])
+        opengl = bool(int(z[f"rays/{tag}/opengl"]))
+        c2w = torch.from_numpy(z[f"rays/{tag}/c2w"])
+        out = recon.generate_rays(H_, W_, f, c2w, normalize=False, opengl=opengl, device=DEV).cpu().numpy()
+        ref = np.concatenate([z[f"rays/{tag}/rays_o"], z[f"rays/{tag}/rays_d"]], 1)
+        np.testing.assert_allclose(out, ref, rtol=2e-6, atol=2e-6)
+        if opengl:      # llff.py:203: the NDC warp of the same rays, near plane 1
+            out = recon.generate_rays(H_, W_, f, c2w, normalize=False, opengl=True, ndc_near=1.0, device=DEV).cpu().numpy()
+            ref = np.concatenate([z[f"rays/{tag}/ndc_o"], z[f"rays/{tag}/ndc_d"]], 1)
+            np.testing.assert_allclose(out, ref, rtol=2e-5, atol=2e-5)
 
 
 @pytest.mark.parametrize("scene", ["C2_vm300", "C4_ndc", "C5_tt640", "shrunk"])

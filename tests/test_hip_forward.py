@@ -22,6 +22,14 @@ def bits_to_mask(words_i32, R_, N):
 def run_hip(recon, c: Case, device="cuda:0"):
     model = build_model(recon, c, device)
     model._debug_masks = True
+    # The fixtures come from the reference on the CPU.  update_stepSize (tensorBase.py:104-116) is the same torch
+    # expression here, but torch.mean over the three axis units rounds differently on the GPU (1 ulp on cubic grids:
+    # sum * (1/3) against sum / 3) — the reference itself would step differently on the two devices.  For the bit-exact
+    # z comparison the kernels get the step the fixture's run used.
+    step_cpu = float(c.cfg_d["stepSize"])
+    if abs(float(model.stepSize) - step_cpu) <= 2e-7 * step_cpu:
+        model.stepSize = torch.tensor(step_cpu, dtype=torch.float32, device=device)
+        model._geom = None
     call = c.call
     torch.manual_seed(call["seed"])
     if call["ndc_ray"] and call["is_train"]:
@@ -52,6 +60,10 @@ def test_forward_parity(recon, name):
     assert np.array_equal(bits_to_mask(ws.dbg_valid, R_, N), c.expect_mask("mid/ray_valid")), "ray_valid mask"
     app = bits_to_mask(ws.dbg_app, R_, N)
     exp_app = c.expect_mask("mid/app_mask")
+    # --- sample positions along the rays: bit-exact (tensorBase.py:198-203, :181-183)
+    z = ws.dbg_z.view(R_, N).cpu().numpy()
+    assert np.array_equal(z.view(np.uint32), c.expect("mid/z").astype(np.float32).view(np.uint32)), \
+        f"z differs in {int((z != c.expect('mid/z')).sum())} of {z.size} samples"
     flips = int((app != exp_app).sum())
     assert flips == 0, f"app_mask flips={flips}, nearest-threshold margin of the fixture={float(c.expect('mid/app_margin')):.2e}"
     assert nvalid == int(c.expect("out/num_valid_samples"))
@@ -103,3 +115,83 @@ def test_renderer_matches_per_chunk_calls(recon):
     with torch.no_grad():
         out2 = recon.OctreeRender_trilinear_fast(rays, model, chunk=64, N_samples=-1, white_bg=True, device="cuda:0")
     assert torch.equal(out2[0], rgb1) and out2[5] == float(n1)
+
+
+@pytest.mark.parametrize("name", ["vm_cubic_eval", "vm_head_MLP", "vm_head_MLP_PE", "vm_cubic_mask_vector", "vm_ndc_eval"])
+def test_render_module_alone(recon, name):
+    """renderModule(pts, viewdirs, features, mask) as a stand-alone call (mlp.py:41-69, 84-107, 126-155): the fixture holds
+    the reference head's output on the shaded samples of the case (gen_golden.py run_case: `mid/rgb_samples` =
+    model.renderModule(xyz_n[app], viewdirs[app], app_features, mask=enc_mask))."""
+    c = Case(name)
+    if "mid/rgb_samples" not in c.raw.files:
+        pytest.skip("no shaded samples in this fixture")
+    dev = "cuda:0"
+    model = build_model(recon, c, dev)
+    R_, N = c.shape
+    app = torch.from_numpy(c.expect_mask("mid/app_mask"))
+    rays = c.rays
+    z = torch.from_numpy(c.expect("mid/z").astype(np.float32))
+    pts = rays[:, None, :3] + rays[:, None, 3:6] * z[..., None]                    # tensorBase.py:205 / :185
+    aabb = torch.tensor(c.cfg_d["aabb"])
+    xyz_n = (pts - aabb[0]) * (2.0 / (aabb[1] - aabb[0])) - 1                       # tensorBase.py:130-131
+    vd = rays[:, 3:6]
+    if c.call["ndc_ray"]:
+        vd = vd / torch.norm(vd, dim=-1, keepdim=True)
+    vd = vd.view(-1, 1, 3).expand(pts.shape)
+    feats = torch.from_numpy(c.expect("mid/app_features"))
+    mk = c.mask_to(dev)
+    enc = None if mk is None else mk["encoding"]
+    out = model.renderModule(xyz_n[app].to(dev), vd[app].to(dev), feats.to(dev), enc).cpu().numpy()
+    np.testing.assert_allclose(out, c.expect("mid/rgb_samples"), rtol=RTOL, atol=ATOL_RGB)
+
+
+@pytest.mark.parametrize("name", ["vm_cubic_eval", "vm_cubic_train", "vm_tnt_inside", "cp_eval"])
+def test_early_ray_termination_is_parity_safe(recon, name):
+    """north_star: wavefront early termination.  Samples behind T < t_stop are not evaluated; they are unshaded (w <= T <
+    1e-7 << rayMarch_weight_thres) but would still add w to acc_map / depth_map (tensorBase.py:377,387), so the cut is only
+    parity-safe far below fp32 resolution of those sums: at t_stop = 1e-7 every output stays inside the 1e-4
+    bar, the shaded set is unchanged, and (on the opaque fixtures) fewer density samples are evaluated."""
+    c = Case(name)
+    dev = "cuda:0"
+    outs = {}
+    for t_stop in (0.0, 1e-7):
+        model = build_model(recon, c, dev)
+        model.t_stop = t_stop
+        call = c.call
+        torch.manual_seed(call["seed"])
+        with torch.no_grad():
+            rgb, depth, nvalid = model(c.rays.to(dev), c.mask_to(dev), white_bg=call["white_bg"], is_train=call["is_train"],
+                                       ndc_ray=call["ndc_ray"], N_samples=call["N_samples"])
+        evaluated = int(model.last["ws"].counters2d[:, 1].sum())
+        outs[t_stop] = (rgb.cpu().numpy(), depth.cpu().numpy(), int(nvalid), evaluated)
+    full, cut = outs[0.0], outs[1e-7]
+    assert cut[2] == full[2] == int(c.expect("out/num_valid_samples"))
+    np.testing.assert_allclose(cut[0], c.expect("out/rgb_map"), rtol=RTOL, atol=ATOL_RGB)
+    np.testing.assert_allclose(cut[1], c.expect("out/depth_map"), rtol=RTOL, atol=1e-5)
+    assert cut[3] <= full[3]
+    print(f"{name}: density samples evaluated {full[3]} -> {cut[3]} with t_stop = 1e-7")
+
+
+def test_early_ray_termination_skips_work_on_an_opaque_scene(recon):
+    """On a dense synthetic field the cut must actually bite (and still render the same image)."""
+    from recon_amd import synthetic as S
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    aabb = torch.tensor(S.LEGO_AABB, device=dev)
+    model = recon.TensorVMSplit(S.lego_args(), aabb, [64] * 3, S.LEGO_NEAR_FAR, dev)
+    S.make_trained_like(model, recon.AlphaGridMask, mask_res=48)
+    with torch.no_grad():
+        model.density_plane[0][:, 0] = 14.0                 # opaque ball
+    allr = S.blender_rays(1)
+    dist = torch.linalg.cross(allr[:, :3], allr[:, 3:6]).norm(dim=-1) / allr[:, 3:6].norm(dim=-1)   # ray - origin distance
+    rays = allr[dist < 0.5][::7][:4096].to(dev).contiguous()       # rays through the ball
+    res = {}
+    for t_stop in (0.0, 1e-7):
+        model.t_stop = t_stop
+        with torch.no_grad():
+            rgb, depth, n = model(rays, None, white_bg=True, is_train=False, N_samples=-1)
+        res[t_stop] = (rgb.cpu(), depth.cpu(), int(n), int(model.last["ws"].counters2d[:, 1].sum()))
+    assert res[1e-7][2] == res[0.0][2]
+    assert res[1e-7][3] < res[0.0][3], (res[1e-7][3], res[0.0][3])      # (the cut acts per block of 64 density samples)
+    assert (res[1e-7][0] - res[0.0][0]).abs().max().item() < 1e-5
+    assert ((res[1e-7][1] - res[0.0][1]).abs() / res[0.0][1].abs().clamp_min(1e-3)).max().item() < 1e-4

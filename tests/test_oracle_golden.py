@@ -80,3 +80,20 @@ def test_reso_helpers():
     assert R.n_to_reso(27000000, cube) == z["n_to_reso_300"].tolist()
     assert R.cal_n_samples([128] * 3, 0.5) == int(z["cal_n_samples_128"])
     assert R.cal_n_samples([300] * 3, 0.5) == int(z["cal_n_samples_300"])
+
+
+def test_tvloss_matches_reference_fixture(recon):
+    """regularizers.TVLoss (the product's restatement of loss.py:120-141) against values and gradients the reference's
+    own TVLoss produced (tests/golden/aux_refs.npz, gen_golden.py aux_refs)."""
+    import os
+    import numpy as np
+    import torch
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "aux_refs.npz"))
+    tv = recon.TVLoss()
+    for tag in ("a", "b", "c"):
+        x = torch.from_numpy(z[f"tv/{tag}/x"]).requires_grad_(True)
+        y = tv(x)
+        y.backward()
+        assert abs(y.item() - float(z[f"tv/{tag}/loss"])) <= 2e-6 * abs(float(z[f"tv/{tag}/loss"])), tag
+        ref = torch.from_numpy(z[f"tv/{tag}/grad"])
+        assert (x.grad - ref).abs().max().item() <= 2e-6 * ref.abs().max().item(), tag
