@@ -474,6 +474,11 @@ def main():
                                            "sample": f"median of {ns2} {args.mode} steps of {bs2} rays, the same "
                                                      f"restatement run eagerly on this GPU (PyTorch-ROCm path)",
                                            "speedup": value / v2}
+            # BASELINE metric, quality half ("rays/sec (train) + PSNR"): equal-iterations PSNR of the HIP path against the
+            # eager PyTorch-ROCm oracle on a frozen synthetic teacher — same init, batches and jitter for both, with one
+            # alpha-mask update and one grid up-sampling inside the run (tests/psnr_parity.py; ~35 s, mostly the eager side)
+            from tests import psnr_parity
+            line["psnr"] = psnr_parity.run(recon_amd, dev=str(dev), grid=64, iters=600, schedule=True, init_grid=48)
         print(json.dumps(line))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -6,13 +6,15 @@ PyTorch-ROCm) on the same seeded inputs as the HIP path at the real sizes: 128^3
 [96]/[288] with the SH head, NDC rays with unequal components, and a 640^3-equivalent non-cubic grid with
 near = 0.01.  Bars: bbox / alpha-mask sample masks identical, shaded-sample mask identical up to threshold ties
 (eager ROCm transcendental kernels are not bit-identical to the CPU ones the fixtures were made with: at most 3
-flips per batch, each within 1e-6 of the 1e-4 threshold), RGB / depth within 1e-4 relative.  Gradients: both sides
-sum ~10^5 fp32 terms per entry in different orders, and a hidden unit whose pre-activation is within rounding of 0
-passes its gradient on one side only (20 M units per batch: a few such ReLU ties occur; at 300^3 one sample's whole
-dL/dV row differed by ~1 % of the tensor's largest entry, identically through the binned and the direct scatter).
-The bar is therefore per tensor: relative L2 error <= 2e-3 and largest entry error <= 2e-2 of the tensor's largest
-entry (tensors whose gradient is below 1e-6 of the step's largest only get the L2 bar against that global scale).
-The small golden cases (tests/test_hip_backward.py) hold the tight bar of 1.5e-4 against the CPU reference."""
+flips per batch, each within 1e-6 of the 1e-4 threshold), RGB / depth within 1e-4 relative.  Gradients: both sides sum ~10^5 fp32 terms
+per entry in different orders; and a hidden unit whose pre-activation is within rounding of 0 is "on" on one side and
+"off" on the other (20 M units per batch: a few such ReLU ties occur).  The test does not widen its bar for that: it
+reads the HIP path's saved hidden layers, lists every unit whose on/off state differs from the oracle's together with
+the oracle's pre-activation (they must all be rounding-level ties, else it is a bug), and then differentiates the
+oracle with the HIP side's on/off pattern — both sides then differentiate the same piecewise-linear function and the
+gradients must agree at the small-case bar (max error <= 2e-4 of the tensor's largest entry, like
+tests/test_hip_backward.py).  Only when the shaded-sample sets themselves differ by a threshold tie (<= 3 samples)
+is the comparison reduced to an L2 bar at one sample's weight."""
 import numpy as np
 import pytest
 import torch
@@ -90,9 +92,31 @@ def test_forward_at_baseline_size(recon, name):
           f"max|drgb|={(rgb - o_rgb).abs().max().item():.2e} max|ddepth|={(depth - o_depth).abs().max().item():.2e}")
 
 
+class _MaskedRelu(torch.autograd.Function):
+    """relu whose derivative is a given on/off pattern (the forward value is the oracle's own)."""
+
+    @staticmethod
+    def forward(ctx, z, on):
+        ctx.save_for_backward(on)
+        return torch.relu(z)
+
+    @staticmethod
+    def backward(ctx, g):
+        (on,) = ctx.saved_tensors
+        return g * on.to(g.dtype), None
+
+
+def _packed_rows(ws, buf, width):
+    """rows of a per-packed-sample buffer in ray-major (= reference) order"""
+    off, cnt = ws.app_offset.cpu().numpy(), ws.app_count.cpu().numpy()
+    idx = np.concatenate([np.arange(o, o + k) for o, k in zip(off, cnt)])
+    return buf.view(-1, width)[torch.from_numpy(idx).to(buf.device)]
+
+
 @pytest.mark.parametrize("name", ["C2_vm300", "C3_cp300_mlp", "C4_ndc", "C5_tt640"])
 def test_train_gradients_at_baseline_size(recon, name):
     """One training forward/backward (jittered samples, MSE against a random target) against the oracle's autograd."""
+    import torch.nn.functional as F
     model, rays, N, ndc, white = _scene(recon, name)
     target = torch.rand(rays.shape[0], 3, generator=torch.Generator().manual_seed(5)).to(DEV)
     torch.manual_seed(3)
@@ -100,24 +124,52 @@ def test_train_gradients_at_baseline_size(recon, name):
         model._jitter_override = torch.rand(1, N)
     model._debug_masks = True
     rgb, _, _ = model(rays, None, white_bg=True, is_train=True, ndc_ray=ndc, N_samples=N)
-    app = bits_to_mask(model.last["ws"].dbg_app, rays.shape[0], N)
+    ws = model.last["ws"]
+    app = bits_to_mask(ws.dbg_app, rays.shape[0], N)
+    FC = model.featureC
+    on1 = _packed_rows(ws, ws.h1s, FC) > 0          # the HIP forward's hidden layers (what its backward reads)
+    on2 = _packed_rows(ws, ws.h2s, FC) > 0
     loss = torch.mean((rgb - target) ** 2)
     loss.backward()
     cfg, params = oracle_of(model, DEV)
     for p in params.values():
         p.requires_grad_(True)
+
+    ties = {}
+
+    def shade_with_hip_pattern(cfg_, params_, pts, viewdirs, feats, enc_mask=None):
+        x = R.mlp_input(cfg_, pts, viewdirs, feats, enc_mask)
+        z1 = F.linear(x, params_["renderModule.mlp.0.weight"], params_["renderModule.mlp.0.bias"])
+        same_set = z1.shape[0] == on1.shape[0]
+        h1 = _MaskedRelu.apply(z1, on1) if same_set else torch.relu(z1)
+        z2 = F.linear(h1, params_["renderModule.mlp.2.weight"], params_["renderModule.mlp.2.bias"])
+        h2 = _MaskedRelu.apply(z2, on2) if same_set else torch.relu(z2)
+        if same_set:
+            for tag, z, on in (("layer 1", z1, on1), ("layer 2", z2, on2)):
+                diff = (z.detach() > 0) != on
+                ties[tag] = (int(diff.sum()), z.detach()[diff].abs().cpu().numpy(), z.detach().abs().mean().item(),
+                             torch.nonzero(diff)[:8].cpu().numpy())
+        return torch.sigmoid(F.linear(h2, params_["renderModule.mlp.4.weight"], params_["renderModule.mlp.4.bias"]))
+
     torch.manual_seed(3)
     jit = torch.rand(1, N).to(DEV) if ndc else None
-    o_rgb, _, _, mid = R.render_rays(cfg, params, rays, None, white_bg=True, is_train=True, ndc_ray=ndc, n_samples=N,
-                                     jitter=jit, keep=True)
+    orig = R.shade
+    R.shade = shade_with_hip_pattern
+    try:
+        o_rgb, _, _, mid = R.render_rays(cfg, params, rays, None, white_bg=True, is_train=True, ndc_ray=ndc, n_samples=N,
+                                         jitter=jit, keep=True)
+    finally:
+        R.shade = orig
     o_loss = torch.mean((o_rgb - target) ** 2)
     o_loss.backward()
     assert abs(loss.item() - o_loss.item()) <= 1e-5 * abs(o_loss.item())
-    # a shaded-sample threshold tie (see the module docstring) adds or removes one sample's whole contribution on
-    # one side: with ties the factor-tensor gradients are compared in the L2 sense only, at one sample's weight
     flips = int((app != mid["app_mask"].cpu().numpy()).sum())
     assert flips <= 3, flips
-    l2_bar, max_bar = (2e-3, 2e-2) if flips == 0 else (2e-2, None)
+    # every hidden unit whose on/off state differs between the two forwards must be a rounding-level tie
+    for tag, (n_diff, zs, zmean, where) in ties.items():
+        print(f"{name} {tag}: {n_diff} of {on1.numel()} units differ in on/off state; |pre-activation| there "
+              f"{zs[:8]} (layer mean |z| {zmean:.3f}); first (sample, unit): {where.tolist()}")
+        assert n_diff <= 64 and (zs <= 2e-6 * max(zmean, 1.0)).all(), (tag, n_diff, zs.max() if n_diff else 0.0)
     top = max(params[k].grad.abs().max().item() for k, _ in model.named_parameters())
     worst = {}
     for k, p in model.named_parameters():
@@ -126,9 +178,11 @@ def test_train_gradients_at_baseline_size(recon, name):
         assert scale > 0, k
         err = (g - og)
         worst[k] = err.abs().max().item() / scale
-        if scale >= 1e-6 * top:
-            assert max_bar is None or worst[k] <= max_bar, (k, worst[k], scale)
-            assert err.norm().item() <= l2_bar * og.norm().item(), (k, err.norm().item(), og.norm().item())
-        else:
-            assert err.norm().item() <= l2_bar * max(og.norm().item(), 1e-6 * top), (k, err.norm().item(), og.norm().item())
+        if flips == 0 and ties:      # same sample set, same on/off pattern: the small-case bar
+            if scale >= 1e-6 * top:
+                assert worst[k] <= 2e-4, (k, worst[k], scale)
+            else:
+                assert err.abs().max().item() <= 2e-4 * 1e-6 * top + 2e-4 * scale, (k, err.abs().max().item(), scale)
+        else:                        # a shaded-sample threshold tie adds / removes one sample's whole contribution
+            assert err.norm().item() <= 2e-2 * max(og.norm().item(), 1e-6 * top), (k, err.norm().item(), og.norm().item())
     print(name, f"mask flips {flips}; worst gradient error / max|grad|:", max(worst.values()), max(worst, key=worst.get))
