@@ -145,6 +145,8 @@ _SIGS = {
     "tf_appfeature_points": [C.POINTER(TfShade), _fp, C.c_int, _fp, _fp],
     "tf_shade_points": [C.POINTER(TfShade), _fp, _fp, _fp, C.c_int, _fp, _fp],
     "tf_alpha_points": [C.POINTER(TfField), _fp, C.c_int, C.c_float, _fp, _fp],
+    "tf_alpha_lattice": [C.POINTER(TfField), _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp],
+    "tf_alpha_pool_threshold": [_fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp, _fp],
     "tf_sample_alpha_points": [_fp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3), _fp,
                                C.c_int, _fp, _fp],
     "tf_filter_rays": [C.POINTER(TfField), _fp, C.c_int, C.c_int, C.c_int, _fp, _fp],

@@ -37,6 +37,102 @@ __global__ __launch_bounds__(256) void alpha_points_kernel(const TfField F, cons
     }
 }
 
+// getDenseAlpha (tensorBase.py:215-230) without the (G^3, 3) point list: lattice node (ix, iy, iz) sits at
+// aabb_lo (1 - s) + aabb_hi s with s = lin_a[i_a] — the caller's three 1-D torch.linspace(0, 1, G_a) tables, so the
+// points are bit for bit the reference's — and its alpha goes to out[iz][iy][ix], the transposed layout
+// updateAlphaMask continues with (:236-237).  4 lanes per node.
+__global__ __launch_bounds__(256) void alpha_lattice_kernel(const TfField F, const float* __restrict__ lin_x,
+                                                            const float* __restrict__ lin_y, const float* __restrict__ lin_z,
+                                                            int gx, int gy, int gz, float length, float* __restrict__ out) {
+    const long long n = (long long)gx * gy * gz;
+    const long long groups = (n + 63) / 64;
+    for (long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); g < groups; g += (long long)gridDim.x * 4) {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const long long node = g * 64 + s * 16 + (lane >> 2);          // = (iz * gy + iy) * gx + ix
+            float part = 0.f;
+            bool hit = false;
+            if (node < n) {
+                const int ix = (int)(node % gx), iy = (int)((node / gx) % gy), iz = (int)(node / ((long long)gx * gy));
+                const float sv[3] = {lin_x[ix], lin_y[iy], lin_z[iz]};
+                float p[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float lo = F.aabb_lo[a] * (1.f - sv[a]);          // aabb[0] * (1 - samples) + aabb[1] * samples
+                    const float hi = F.aabb_hi[a] * sv[a];
+                    p[a] = lo + hi;
+                }
+                hit = F.alpha_cells == nullptr || alpha_hit(F, p);
+                if (hit) {
+                    float u[3];
+                    normalize(F, p, u);
+                    part = density_partial(F.model, F.density, F.grid, u, lane & 3);
+                }
+            }
+            const float f = quad_sum(part);
+            if (node < n && (lane & 3) == 0) {
+                const float sigma = hit ? density_act(F, f) : 0.f;
+                out[node] = 1.f - expf(-sigma * length);
+            }
+        }
+    }
+}
+
+// updateAlphaMask's tail (tensorBase.py:236-254) in one pass over the (gz, gy, gx) alpha volume: clamp to [0, 1], 3^3
+// max-pool (stride 1, padding 1), threshold -> 0 / 1 volume; and, over the kept voxels, their count and the index box
+// [min, max] per axis (the reference's amin / amax of the kept lattice points are the lattice coordinates at those
+// indices: the tables are monotone).  stats: {count, min_x, min_y, min_z, max_x, max_y, max_z}, preset by the caller.
+__global__ __launch_bounds__(256) void alpha_pool_kernel(const float* __restrict__ alpha, int gx, int gy, int gz, float thres,
+                                                         float* __restrict__ vol, int* __restrict__ stats) {
+    const long long n = (long long)gx * gy * gz;
+    int cnt = 0, lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {-1, -1, -1};
+    for (long long node = (long long)blockIdx.x * blockDim.x + threadIdx.x; node < n; node += (long long)gridDim.x * blockDim.x) {
+        const int ix = (int)(node % gx), iy = (int)((node / gx) % gy), iz = (int)(node / ((long long)gx * gy));
+        float m = -INFINITY;
+        for (int dz = -1; dz <= 1; ++dz) {
+            const int z = iz + dz;
+            if (z < 0 || z >= gz) continue;
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int y = iy + dy;
+                if (y < 0 || y >= gy) continue;
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int x = ix + dx;
+                    if (x < 0 || x >= gx) continue;
+                    const float a = fminf(fmaxf(alpha[((long long)z * gy + y) * gx + x], 0.f), 1.f);
+                    m = fmaxf(m, a);
+                }
+            }
+        }
+        const bool keep = m >= thres;
+        vol[node] = keep ? 1.f : 0.f;
+        if (keep) {
+            ++cnt;
+            lo[0] = min(lo[0], ix); lo[1] = min(lo[1], iy); lo[2] = min(lo[2], iz);
+            hi[0] = max(hi[0], ix); hi[1] = max(hi[1], iy); hi[2] = max(hi[2], iz);
+        }
+    }
+    // wave reduction, then one atomic per wave and statistic
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += __shfl_xor(cnt, o, 64);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = min(lo[a], __shfl_xor(lo[a], o, 64));
+            hi[a] = max(hi[a], __shfl_xor(hi[a], o, 64));
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && cnt > 0) {
+        atomicAdd(&stats[0], cnt);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&stats[1 + a], lo[a]);
+            atomicMax(&stats[4 + a], hi[a]);
+        }
+    }
+}
+
 // F.grid_sample(volume (1,1,Gz,Gy,Gx), pts, align_corners=True, zeros padding), trilinear.  tensorBase.py:41-45
 __global__ __launch_bounds__(256) void sample_alpha_kernel(const float* __restrict__ vol, int gx, int gy, int gz,
                                                            float lx, float ly, float lz, float ix, float iy, float iz,
@@ -196,6 +292,28 @@ int tf_alpha_points(const TfField* field, const float* xyz, int n, float length,
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(alpha_points_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *field, xyz, n, length,
                        out_alpha);
+    return TF_CHECK_LAUNCH();
+}
+
+int tf_alpha_lattice(const TfField* field, const float* lin_x, const float* lin_y, const float* lin_z, int gx, int gy, int gz,
+                     float length, float* out_alpha, tf_stream_t stream) {
+    if (gx <= 0 || gy <= 0 || gz <= 0) return (int)hipErrorInvalidValue;
+    const long long n = (long long)gx * gy * gz;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(alpha_lattice_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *field, lin_x, lin_y,
+                       lin_z, gx, gy, gz, length, out_alpha);
+    return TF_CHECK_LAUNCH();
+}
+
+int tf_alpha_pool_threshold(const float* alpha, int gx, int gy, int gz, float thres, float* volume, int* stats,
+                            tf_stream_t stream) {
+    if (gx <= 0 || gy <= 0 || gz <= 0 || !stats) return (int)hipErrorInvalidValue;
+    const long long n = (long long)gx * gy * gz;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(alpha_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, alpha, gx, gy, gz, thres,
+                       volume, stats);
     return TF_CHECK_LAUNCH();
 }
 

@@ -783,39 +783,73 @@ class TensorBase(nn.Module):
                                         _stream()), "tf_alpha_points")
         return out.view(shape)
 
+    def _lattice_tables(self, grid):
+        """The three torch.linspace(0, 1, G) tables of getDenseAlpha (tensorBase.py:218-222): made on the CPU like the
+        reference's, three small uploads instead of the (G^3, 3) meshgrid (201 MB at 256^3)."""
+        return [torch.linspace(0, 1, int(g)).to(self.device) for g in grid]
+
     @torch.no_grad()
     def getDenseAlpha(self, gridSize=None, mask=None):
-        """models/tensorBase.py:215-230 (one kernel call over the whole lattice instead of one per x-slice)."""
-        gridSize = self.gridSize if gridSize is None else gridSize
-        samples = torch.stack(torch.meshgrid(
-            torch.linspace(0, 1, int(gridSize[0])),
-            torch.linspace(0, 1, int(gridSize[1])),
-            torch.linspace(0, 1, int(gridSize[2])), indexing='ij'), -1).to(self.device)
-        dense_xyz = self.aabb[0] * (1 - samples) + self.aabb[1] * samples
-        alpha = self.compute_alpha(dense_xyz.view(-1, 3), mask, self.stepSize).view(dense_xyz.shape[:-1])
-        return alpha, dense_xyz
+        """models/tensorBase.py:215-230: (alpha (gx, gy, gz), lattice points (gx, gy, gz, 3)).  The alpha values come from
+        one tf_alpha_lattice launch; the point list exists only because this method returns it (updateAlphaMask does
+        not build it)."""
+        grid = [int(g) for g in (self.gridSize if gridSize is None else gridSize)]
+        tabs = self._lattice_tables(grid)
+        alpha_zyx = self._lattice_alpha(grid, tabs, mask)
+        s = torch.stack(torch.meshgrid(*tabs, indexing='ij'), -1)
+        return alpha_zyx.permute(2, 1, 0), self.aabb[0] * (1 - s) + self.aabb[1] * s
+
+    def _lattice_alpha(self, grid, tabs, mask):
+        field = self._field_desc(self._decomp_mask_vectors(mask, self.density_n_comp, self.device))
+        out = torch.empty((grid[2], grid[1], grid[0]), dtype=torch.float32, device=self.device)
+        H.check(H.lib().tf_alpha_lattice(C.byref(field), tabs[0].data_ptr(), tabs[1].data_ptr(), tabs[2].data_ptr(),
+                                         grid[0], grid[1], grid[2], float(self.stepSize), out.data_ptr(), _stream()),
+                "tf_alpha_lattice")
+        return out
 
     @torch.no_grad()
     def updateAlphaMask(self, gridSize=(200, 200, 200), mask=None):
-        """models/tensorBase.py:233-256."""
-        alpha, dense_xyz = self.getDenseAlpha(gridSize, mask)
-        dense_xyz = dense_xyz.transpose(0, 2).contiguous()
-        alpha = alpha.clamp(0, 1).transpose(0, 2).contiguous()[None, None]
-        total_voxels = gridSize[0] * gridSize[1] * gridSize[2]
-        ks = 3
-        alpha = torch.nn.functional.max_pool3d(alpha, kernel_size=ks, padding=ks // 2, stride=1).view(list(gridSize)[::-1])
-        alpha[alpha >= self.alphaMask_thres] = 1
-        alpha[alpha < self.alphaMask_thres] = 0
-        self.alphaMask = AlphaGridMask(self.device, self.aabb, alpha)
-        valid_xyz = dense_xyz[alpha > 0.5]
-        if valid_xyz.shape[0] == 0:  # the reference fails here too (amin of an empty tensor)
+        """models/tensorBase.py:233-256 in two launches: the lattice alphas (tf_alpha_lattice, written in the (z, y, x)
+        order the mask volume uses) and clamp + 3^3 max-pool + threshold + kept-voxel box (tf_alpha_pool_threshold).
+        Returns the tight box of the kept lattice points, like the reference."""
+        grid = [int(g) for g in gridSize]
+        tabs = self._lattice_tables(grid)
+        alpha_zyx = self._lattice_alpha(grid, tabs, mask)
+        occupancy = torch.empty_like(alpha_zyx)
+        big = 2 ** 31 - 1
+        stats = torch.tensor([0, big, big, big, -1, -1, -1], dtype=torch.int32).to(self.device)
+        H.check(H.lib().tf_alpha_pool_threshold(alpha_zyx.data_ptr(), grid[0], grid[1], grid[2], float(self.alphaMask_thres),
+                                                occupancy.data_ptr(), stats.data_ptr(), _stream()), "tf_alpha_pool_threshold")
+        kept, *box = stats.tolist()
+        if kept == 0:   # the reference fails here too (amin of an empty tensor)
             raise IndexError("updateAlphaMask: no voxel reaches alphaMask_thres=%g" % self.alphaMask_thres)
-        xyz_min = valid_xyz.amin(0)
-        xyz_max = valid_xyz.amax(0)
-        new_aabb = torch.stack((xyz_min, xyz_max))
-        total = torch.sum(alpha)
-        print(f"bbox: {xyz_min, xyz_max} alpha rest %%%f" % (total / total_voxels * 100))
-        return new_aabb
+        self.alphaMask = AlphaGridMask(self.device, self.aabb, occupancy)
+        # the kept points' per-axis extremes are the lattice coordinates at the extreme kept indices
+        frac = torch.stack([torch.stack([tabs[a][box[a]] for a in range(3)]),
+                            torch.stack([tabs[a][box[3 + a]] for a in range(3)])])
+        tight = self.aabb[0] * (1 - frac) + self.aabb[1] * frac
+        print("alpha mask %dx%dx%d: %.3f %% of the voxels kept, tight box %s .. %s" %
+              (grid[0], grid[1], grid[2], 100.0 * kept / (grid[0] * grid[1] * grid[2]),
+               [round(v, 4) for v in tight[0].tolist()], [round(v, 4) for v in tight[1].tolist()]))
+        return tight
+
+    def _voxel_window(self, box):
+        """[first, stop) voxel indices per axis that `box` covers on the current grid: the lower corner rounds to the
+        nearest voxel, the upper one to the nearest voxel + 1, clipped to the grid (tensoRF.py:293-297)."""
+        first = torch.round((box[0] - self.aabb[0]) / self.units).long()
+        stop = torch.minimum(torch.round((box[1] - self.aabb[0]) / self.units).long() + 1, self.gridSize)
+        return first, stop
+
+    def _adopt_window(self, box, first, stop):
+        """The field's box after a crop: `box` itself when the alpha mask was built on the field's own grid, else the
+        voxel-aligned box of the window (tensoRF.py:313-327); then update_stepSize for the cropped grid."""
+        if not torch.all(self.alphaMask.gridSize == self.gridSize):
+            span = self.gridSize - 1
+            f0, f1 = first / span, (stop - 1) / span
+            box = torch.stack(((1 - f0) * self.aabb[0] + f0 * self.aabb[1], (1 - f1) * self.aabb[0] + f1 * self.aabb[1]))
+        self.aabb = box
+        size = stop - first
+        self.update_stepSize((size[0], size[1], size[2]))
 
     @torch.no_grad()
     def filtering_rays(self, all_rays, all_rgbs, N_samples=256, chunk=10240 * 5, bbox_only=False):
@@ -886,82 +920,61 @@ class TensorVMSplit(TensorBase):
         return grad_vars
 
 
-    # ---- regularisers on the factor tensors (models/tensoRF.py:175-205; SURVEY row f-3, torch ops for now) ----
+    # ---- regularisers on the factor tensors (behaviour of models/tensoRF.py:175-205; the one-pass HIP form is
+    #      regularizers.fused_regularizers / add_regularizer_grads_) ----
+    @staticmethod
+    def _mean_abs_offdiag_gram(line):
+        """mean |<v_a, v_b>| over the ordered pairs a != b of the C component vectors of one line tensor (1, C, G, 1)."""
+        v = line.flatten(2).squeeze(0)                    # (C, G)
+        n = v.shape[0]
+        off = ~torch.eye(n, dtype=torch.bool, device=v.device)
+        return (v @ v.t())[off].abs().mean()          # (the diagonal |v_a|^2 dwarfs the rest: never sum it and subtract)
+
     def vectorDiffs(self, vector_comps):
-        total = 0
-        for idx in range(len(vector_comps)):
-            n_comp, n_size = vector_comps[idx].shape[1:-1]
-            v = vector_comps[idx].reshape(n_comp, n_size)
-            dotp = torch.matmul(v, v.transpose(-1, -2))
-            non_diagonal = dotp.view(-1)[1:].view(n_comp - 1, n_comp + 1)[..., :-1]
-            total = total + torch.mean(torch.abs(non_diagonal))
-        return total
+        return sum(self._mean_abs_offdiag_gram(line) for line in vector_comps)
 
     def vector_comp_diffs(self):
         return self.vectorDiffs(self.density_line) + self.vectorDiffs(self.app_line)
 
     def density_L1(self):
-        total = 0
-        for idx in range(len(self.density_plane)):
-            total = total + torch.mean(torch.abs(self.density_plane[idx])) + torch.mean(torch.abs(self.density_line[idx]))
-        return total
+        return sum(t.abs().mean() for t in list(self.density_plane) + list(self.density_line))
 
     def TV_loss_density(self, reg):
-        total = 0
-        for idx in range(len(self.density_plane)):
-            total = total + reg(self.density_plane[idx]) * 1e-2
-        return total
+        return 1e-2 * sum(reg(p) for p in self.density_plane)
 
     def TV_loss_app(self, reg):
-        total = 0
-        for idx in range(len(self.app_plane)):
-            total = total + reg(self.app_plane[idx]) * 1e-2
-        return total
+        return 1e-2 * sum(reg(p) for p in self.app_plane)
 
-    # ---- coarse-to-fine schedule (models/tensoRF.py:267-327; torch resize / crop, channel-last storage kept) ----
+    # ---- coarse-to-fine schedule (behaviour of models/tensoRF.py:267-327; channel-last storage kept) ----
+    @staticmethod
+    def _resized(t, height, width):
+        """bilinear, align_corners=True resize of a (1, C, H, W) factor tensor -> new channel-last Parameter"""
+        return channel_last_param(torch.nn.functional.interpolate(t.data, size=(int(height), int(width)), mode='bilinear',
+                                                                   align_corners=True))
+
     @torch.no_grad()
     def up_sampling_VM(self, plane_coef, line_coef, res_target):
-        for i in range(len(self.vecMode)):
-            vec_id = self.vecMode[i]
-            mat_id_0, mat_id_1 = self.matMode[i]
-            plane_coef[i] = channel_last_param(torch.nn.functional.interpolate(
-                plane_coef[i].data, size=(int(res_target[mat_id_1]), int(res_target[mat_id_0])), mode='bilinear',
-                align_corners=True))
-            line_coef[i] = channel_last_param(torch.nn.functional.interpolate(
-                line_coef[i].data, size=(int(res_target[vec_id]), 1), mode='bilinear', align_corners=True))
+        for i, ((ax_w, ax_h), ax_l) in enumerate(zip(self.matMode, self.vecMode)):
+            plane_coef[i] = self._resized(plane_coef[i], res_target[ax_h], res_target[ax_w])
+            line_coef[i] = self._resized(line_coef[i], res_target[ax_l], 1)
         return plane_coef, line_coef
 
     @torch.no_grad()
     def upsample_volume_grid(self, res_target):
-        self.app_plane, self.app_line = self.up_sampling_VM(self.app_plane, self.app_line, res_target)
-        self.density_plane, self.density_line = self.up_sampling_VM(self.density_plane, self.density_line, res_target)
+        self.up_sampling_VM(self.app_plane, self.app_line, res_target)
+        self.up_sampling_VM(self.density_plane, self.density_line, res_target)
         self.update_stepSize(res_target)
-        print(f'upsamping to {res_target}')
+        print("grid resized to", [int(r) for r in res_target])
 
     @torch.no_grad()
     def shrink(self, new_aabb):
-        xyz_min, xyz_max = new_aabb
-        t_l, b_r = (xyz_min - self.aabb[0]) / self.units, (xyz_max - self.aabb[0]) / self.units
-        t_l, b_r = torch.round(torch.round(t_l)).long(), torch.round(b_r).long() + 1
-        b_r = torch.stack([b_r, self.gridSize]).amin(0)
-        for i in range(len(self.vecMode)):
-            mode0 = self.vecMode[i]
-            self.density_line[i] = channel_last_param(self.density_line[i].data[..., t_l[mode0]:b_r[mode0], :])
-            self.app_line[i] = channel_last_param(self.app_line[i].data[..., t_l[mode0]:b_r[mode0], :])
-            mode0, mode1 = self.matMode[i]
-            self.density_plane[i] = channel_last_param(
-                self.density_plane[i].data[..., t_l[mode1]:b_r[mode1], t_l[mode0]:b_r[mode0]])
-            self.app_plane[i] = channel_last_param(
-                self.app_plane[i].data[..., t_l[mode1]:b_r[mode1], t_l[mode0]:b_r[mode0]])
-        if not torch.all(self.alphaMask.gridSize == self.gridSize):
-            t_l_r, b_r_r = t_l / (self.gridSize - 1), (b_r - 1) / (self.gridSize - 1)
-            correct_aabb = torch.zeros_like(new_aabb)
-            correct_aabb[0] = (1 - t_l_r) * self.aabb[0] + t_l_r * self.aabb[1]
-            correct_aabb[1] = (1 - b_r_r) * self.aabb[0] + b_r_r * self.aabb[1]
-            new_aabb = correct_aabb
-        newSize = b_r - t_l
-        self.aabb = new_aabb
-        self.update_stepSize((newSize[0], newSize[1], newSize[2]))
+        """Crops every factor tensor to the voxel window of `new_aabb` (tensoRF.py:291-327)."""
+        first, stop = self._voxel_window(new_aabb)
+        for i, ((ax_w, ax_h), ax_l) in enumerate(zip(self.matMode, self.vecMode)):
+            for lines, planes in ((self.density_line, self.density_plane), (self.app_line, self.app_plane)):
+                lines[i] = channel_last_param(lines[i].data[:, :, first[ax_l]:stop[ax_l], :])
+                planes[i] = channel_last_param(planes[i].data[:, :, first[ax_h]:stop[ax_h], first[ax_w]:stop[ax_w]])
+        self._adopt_window(new_aabb, first, stop)
 
 
 class TensorCP(TensorBase):
@@ -999,51 +1012,29 @@ class TensorCP(TensorBase):
         return grad_vars
 
     def density_L1(self):
-        total = 0
-        for idx in range(len(self.density_line)):
-            total = total + torch.mean(torch.abs(self.density_line[idx]))
-        return total
+        return sum(t.abs().mean() for t in self.density_line)
 
     def TV_loss_density(self, reg):
-        total = 0
-        for idx in range(len(self.density_line)):
-            total = total + reg(self.density_line[idx]) * 1e-3
-        return total
+        return 1e-3 * sum(reg(l) for l in self.density_line)
 
     def TV_loss_app(self, reg):
-        total = 0
-        for idx in range(len(self.app_line)):
-            total = total + reg(self.app_line[idx]) * 1e-3
-        return total
+        return 1e-3 * sum(reg(l) for l in self.app_line)
 
     @torch.no_grad()
     def upsample_volume_grid(self, res_target):
-        """models/tensoRF.py:418-435."""
-        for i in range(len(self.vecMode)):
-            vec_id = self.vecMode[i]
+        """behaviour of models/tensoRF.py:418-435"""
+        for i, ax_l in enumerate(self.vecMode):
             for lines in (self.density_line, self.app_line):
                 lines[i] = channel_last_param(torch.nn.functional.interpolate(
-                    lines[i].data, size=(int(res_target[vec_id]), 1), mode='bilinear', align_corners=True))
+                    lines[i].data, size=(int(res_target[ax_l]), 1), mode='bilinear', align_corners=True))
         self.update_stepSize(res_target)
-        print(f'upsamping to {res_target}')
+        print("grid resized to", [int(r) for r in res_target])
 
     @torch.no_grad()
     def shrink(self, new_aabb):
-        """models/tensoRF.py:437-466."""
-        xyz_min, xyz_max = new_aabb
-        t_l, b_r = (xyz_min - self.aabb[0]) / self.units, (xyz_max - self.aabb[0]) / self.units
-        t_l, b_r = torch.round(torch.round(t_l)).long(), torch.round(b_r).long() + 1
-        b_r = torch.stack([b_r, self.gridSize]).amin(0)
-        for i in range(len(self.vecMode)):
-            mode0 = self.vecMode[i]
-            self.density_line[i] = channel_last_param(self.density_line[i].data[..., t_l[mode0]:b_r[mode0], :])
-            self.app_line[i] = channel_last_param(self.app_line[i].data[..., t_l[mode0]:b_r[mode0], :])
-        if not torch.all(self.alphaMask.gridSize == self.gridSize):
-            t_l_r, b_r_r = t_l / (self.gridSize - 1), (b_r - 1) / (self.gridSize - 1)
-            correct_aabb = torch.zeros_like(new_aabb)
-            correct_aabb[0] = (1 - t_l_r) * self.aabb[0] + t_l_r * self.aabb[1]
-            correct_aabb[1] = (1 - b_r_r) * self.aabb[0] + b_r_r * self.aabb[1]
-            new_aabb = correct_aabb
-        newSize = b_r - t_l
-        self.aabb = new_aabb
-        self.update_stepSize((newSize[0], newSize[1], newSize[2]))
+        """behaviour of models/tensoRF.py:437-466"""
+        first, stop = self._voxel_window(new_aabb)
+        for i, ax_l in enumerate(self.vecMode):
+            for lines in (self.density_line, self.app_line):
+                lines[i] = channel_last_param(lines[i].data[:, :, first[ax_l]:stop[ax_l], :])
+        self._adopt_window(new_aabb, first, stop)

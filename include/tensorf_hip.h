@@ -262,6 +262,16 @@ int tf_shade_backward(const TfShade* shade, const float* rays, int ndc, const in
 /* compute_alpha on world-space points: alpha mask test, normalise, density, activation, 1-exp(-sigma*length).
  * tensorBase.py:298-318 (used by getDenseAlpha / updateAlphaMask :215-256). */
 int tf_alpha_points(const TfField* field, const float* xyz, int n, float length, float* out_alpha, tf_stream_t stream);
+/* getDenseAlpha (tensorBase.py:215-230) on the device: alpha of every node of the (gx, gy, gz) lattice of the field's
+ * box — node (ix, iy, iz) at aabb_lo (1 - s) + aabb_hi s, s = lin_x[ix] / lin_y[iy] / lin_z[iz] (the caller's
+ * torch.linspace(0, 1, G) tables, device pointers) — written as out_alpha[iz][iy][ix], the layout updateAlphaMask
+ * continues with (:236-237).  No (G^3, 3) point list is built or copied. */
+int tf_alpha_lattice(const TfField* field, const float* lin_x, const float* lin_y, const float* lin_z, int gx, int gy, int gz,
+                     float length, float* out_alpha, tf_stream_t stream);
+/* updateAlphaMask's tail (tensorBase.py:236-254): clamp, 3^3 max-pool, threshold -> volume (gz, gy, gx) of 0 / 1, and
+ * stats[7] = {kept voxels, min ix, iy, iz, max ix, iy, iz} of the kept voxels (preset to {0, INT_MAX x3, -1 x3}). */
+int tf_alpha_pool_threshold(const float* alpha, int gx, int gy, int gz, float thres, float* volume, int* stats,
+                            tf_stream_t stream);
 /* AlphaGridMask.sample_alpha: trilinear grid_sample of the float volume (Gz,Gy,Gx), align_corners, zero padding;
  * lo / inv = the mask's aabb[0] and 2/aabbSize.  tensorBase.py:41-48. */
 int tf_sample_alpha_points(const float* volume, int gx, int gy, int gz, const float lo[3], const float inv[3],
