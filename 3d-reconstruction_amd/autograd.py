@@ -18,27 +18,44 @@ from .field import _stream, is_channel_last
 N_REP = 64   # replicas of the line-gradient tensors (TfFactorGrads.n_rep)
 
 
+_LAYOUTS = {}     # tuple of (name, shape, stride) -> (offs, total, line_len, [(name, size, stride, offset)])
+
+
+def _grad_layout(named):
+    """Where every parameter's gradient sits in the step's flat buffer: line tensors first (the direct-scatter
+    replicas follow the buffer), everything 64-float aligned; gradients are laid out like their parameters (channel-last
+    for the factor tensors).  Cached per parameter set: building 19 views costs ~0.1 ms of host time per step otherwise."""
+    key = tuple((n, tuple(p.shape), tuple(p.stride())) for n, p in named)
+    hit = _LAYOUTS.get(key)
+    if hit is not None:
+        return hit
+    order = sorted(named, key=lambda kv: 0 if '_line.' in kv[0] else 1)
+    offs, total, line_len, views = {}, 0, 0, []
+    for name, p in order:
+        offs[name] = total
+        if p.dim() == 4 and is_channel_last(p):
+            b, c, h, w = p.shape
+            stride = (h * w * c, 1, w * c, c)
+        else:
+            stride = tuple(torch.empty(p.shape, device='meta').stride())
+        views.append((name, tuple(p.shape), stride, total))
+        total += (p.numel() + 63) // 64 * 64
+        if '_line.' in name:
+            line_len = total
+    if len(_LAYOUTS) > 64:
+        _LAYOUTS.clear()
+    _LAYOUTS[key] = (offs, total, line_len, views)
+    return _LAYOUTS[key]
+
+
 def _grad_buffers(named, n_rep=N_REP):
     """One zero-filled allocation: [line gradients | all other gradients | n_rep replicas of the line block].
     The direct-scatter kernels spread line-gradient atomics over the replicas; tf_reduce_replicas folds them
     into the head of the buffer, so flat[:grad_len] is every parameter gradient of the step, contiguous (one
     all-reduce).  The binned scatter flushes each line bucket once per work item and needs no replicas."""
-    named = sorted(named, key=lambda kv: 0 if '_line.' in kv[0] else 1)
-    offs, total, line_len = {}, 0, 0
-    for name, p in named:
-        offs[name] = total
-        total += (p.numel() + 63) // 64 * 64
-        if '_line.' in name:
-            line_len = total
+    offs, total, line_len, layout = _grad_layout(named)
     flat = torch.zeros(total + n_rep * line_len, dtype=torch.float32, device=named[0][1].device)
-    views = {}
-    for name, p in named:
-        chunk = flat[offs[name]:offs[name] + p.numel()]
-        if p.dim() == 4 and is_channel_last(p):
-            b, c, h, w = p.shape
-            views[name] = chunk.view(b, h, w, c).permute(0, 3, 1, 2)
-        else:
-            views[name] = chunk.view(p.shape)
+    views = {name: torch.as_strided(flat, size, stride, off) for name, size, stride, off in layout}
     return views, flat, offs, total, line_len
 
 

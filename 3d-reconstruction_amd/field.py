@@ -281,6 +281,7 @@ class TensorBase(nn.Module):
         self._train_ws = {}
         self._named_cache = None
         self._pack_cache = {}
+        self._plans = {}
         self._ztab_cache = {}
         self.last = None               # workspace of the most recent forward (tests / bench statistics)
         self.kernel_events = None      # bench: dict name -> [(start_event, end_event)] when enabled
@@ -318,6 +319,7 @@ class TensorBase(nn.Module):
         self.nSamples = int((self.aabbDiag / self.stepSize).item()) + 1
         self._geom = None
         self._ws_cache, self._train_ws, self._named_cache = {}, {}, None   # sized for the previous grid
+        self._plans = {}
 
     def init_svd_volume(self, res, device):
         pass
@@ -428,12 +430,13 @@ class TensorBase(nn.Module):
             f.alpha_cells = None
         return f
 
-    def _packed_many(self, reqs, zero=None):
+    def _packed_many(self, reqs, zero=None, job_out=None):
         """Zero-padded copies [rows_pad][kpad16(cols)] of weight matrices (or their transposes [kpad16(cols)][rows_pad]),
         refreshed when the source changed — all stale ones in ONE tf_pack_matrices launch.  reqs: (key, src, rows_pad,
         transpose)."""
         out, todo = [], []
-        capturing = torch.cuda.is_current_stream_capturing()
+        capturing = torch.cuda.is_current_stream_capturing() or job_out is not None     # a plan packs everything once
+        watch = []
         for key, src, rows_pad, transpose in reqs:
             rows, cols = src.shape
             kp = (cols + 15) // 16 * 16
@@ -450,6 +453,7 @@ class TensorBase(nn.Module):
             todo.append((src.detach().contiguous(), dst, rows, cols, rows_pad, transpose))
             self._pack_cache[key] = (tag, dst)
             out.append(dst)
+            watch.append([src, src._version, key, rows_pad, kp, transpose])
         self._zero_rode = False
         for k0 in range(0, len(todo), H.PACK_MAX):
             job = H.TfPackJob()
@@ -462,11 +466,67 @@ class TensorBase(nn.Module):
                 it.src, it.dst, it.rows, it.cols, it.rows_pad, it.transpose = s_.data_ptr(), dst.data_ptr(), rows, cols, \
                     rows_pad, int(transpose)
             H.check(H.lib().tf_pack_matrices(C.byref(job), _stream()), "tf_pack_matrices")
+            if job_out is not None and k0 == 0 and len(todo) <= H.PACK_MAX:
+                job_out.job, job_out.watch = job, watch        # (sources are parameters: contiguous, pointers stable)
+        if job_out is not None and not hasattr(job_out, "job"):
+            job_out.job, job_out.watch = None, watch
         return out
+
+    # ---- cached launch descriptors for the common call (no FreeNeRF masks) --------------------------------------
+    class _Plan:
+        __slots__ = ("key", "field", "shade", "keep", "job", "watch")
+
+    def _plan(self, train, dev):
+        """TfField / TfShade / the weight-pack job of a forward without masks, built once and reused until the alpha
+        mask, the geometry or a parameter OBJECT is replaced (updateAlphaMask, shrink, upsample_volume_grid, load): the
+        eager train step spent 0.25 ms of host time per call rebuilding these ctypes structs (round-1 verdict #10)."""
+        named = self._named_cache
+        params = named[1] if named is not None else list(self.parameters())
+        key = (self.alphaMask, self._geom, dev) + tuple(params)
+        pl = self._plans.get(train)
+        if pl is not None and self._geom is not None and len(pl.key) == len(key) and all(a is b for a, b in zip(pl.key, key)):
+            return pl
+        pl = TensorBase._Plan()
+        pl.field = self._field_desc([None, None, None])
+        shade, keep = self._shade_desc([None, None, None], None, dev, train=train, pack=True, zero=None, job_out=pl)
+        pl.shade, pl.keep = shade, keep
+        params = self._named_cache[1] if self._named_cache is not None else list(self.parameters())
+        pl.key = (self.alphaMask, self._geom, dev) + tuple(params)
+        self._plans[train] = pl
+        return pl
+
+    def _refresh_packed(self, pl, zero):
+        """One tf_pack_matrices launch when a watched weight changed (every training step) — the forward's zero block
+        rides on it — else just the zero fill."""
+        job, watch = pl.job, pl.watch
+        stale = torch.cuda.is_current_stream_capturing()
+        if not stale:
+            for w in watch:
+                if w[0]._version != w[1]:
+                    stale = True
+                    break
+        if job is None or not stale:
+            zero.zero_()
+            return
+        job.zero, job.n_zero = zero.data_ptr(), zero.numel()
+        H.check(H.lib().tf_pack_matrices(C.byref(job), _stream()), "tf_pack_matrices")
+        for w in watch:
+            w[1] = w[0]._version
+        self._pack_tags_from(watch)               # keep the generic cache's tags truthful
+
+    def _pack_tags_from(self, watch):
+        for w in watch:
+            src, key, rows_pad, kp, transpose = w[0], w[2], w[3], w[4], w[5]
+            hit = self._pack_cache.get(key)
+            if hit is not None:
+                self._pack_cache[key] = ((src.data_ptr(), src._version, rows_pad, kp, transpose), hit[1])
 
     def invalidate_packed_weights(self):
         """Forget which weights the padded copies were made from (their buffers are kept and refilled on next use)."""
         self._pack_cache = {k: (None, v[1]) for k, v in self._pack_cache.items()}
+        for pl in self._plans.values():
+            for w in pl.watch:
+                w[1] = -1
 
     def _pe_blocks(self, enc_mask, dev):
         """Order of the encoding blocks per head (models/mlp.py:41-66, 84-103, 126-153)."""
@@ -494,7 +554,7 @@ class TensorBase(nn.Module):
             blocks.append((src, freqs, mv))
         return blocks, keep
 
-    def _shade_desc(self, app_masks, enc_mask, dev, train=False, pack=True, zero=None):
+    def _shade_desc(self, app_masks, enc_mask, dev, train=False, pack=True, zero=None, job_out=None):
         """pack=False: dimensions only (size / support queries), no weight copies are made or refreshed."""
         s = H.TfShade()
         s.model = H.MODEL_CP if self._is_cp() else H.MODEL_VM
@@ -510,7 +570,7 @@ class TensorBase(nn.Module):
         reqs = [('basis', self.basis_mat.weight, 16 * nb, False)]
         if self.shadingMode in ('SH', 'RGB'):
             if pack:
-                basis, = self._packed_many(reqs)
+                basis, = self._packed_many(reqs, job_out=job_out)
                 s.basis = basis.data_ptr()
                 keep.append(basis)
             s.head = H.HEAD_SH if self.shadingMode == 'SH' else H.HEAD_RGB
@@ -534,7 +594,7 @@ class TensorBase(nn.Module):
         reqs += [('w1', mlp[0].weight, self.featureC, False), ('w2', mlp[2].weight, self.featureC, False)]
         if train:     # the backward GEMMs dH1 = W2^T dZ2, dX = W1^T dZ1 read the transposes
             reqs += [('w1t', mlp[0].weight, self.featureC, True), ('w2t', mlp[2].weight, self.featureC, True)]
-        packed = self._packed_many(reqs, zero)
+        packed = self._packed_many(reqs, zero, job_out=job_out)
         keep += packed
         s.basis, s.w1, s.w2 = packed[0].data_ptr(), packed[1].data_ptr(), packed[2].data_ptr()
         if train:
@@ -668,16 +728,23 @@ class TensorBase(nn.Module):
         else:
             use_bg = bool(white_bg or (is_train and bool(torch.rand((1,)) < 0.5)))
 
-        field = self._field_desc(den_masks)
+        plan = self._plan(save_valid, dev) if mask is None else None       # (also makes the host copy of the geometry)
+        if plan is None and self._geom is None:
+            self._field_desc([None, None, None])
         ws = self._workspace(R, N, dev, save_valid)
         if save_valid and self._sort_stream is not None and not torch.cuda.is_current_stream_capturing():
             # a training forward whose backward never ran may have left its early sorts in flight on this workspace
             torch.cuda.current_stream().wait_stream(self._sort_stream)
-        self._zero_rode = False
-        shade, keep = self._shade_desc(app_masks, enc_mask, dev, train=save_valid, zero=ws.zero_block)
+        if plan is not None:    # cached descriptors; one pack launch when the weights changed, carrying the zero fill
+            field, shade, keep = plan.field, plan.shade, plan.keep
+            self._refresh_packed(plan, ws.zero_block)
+        else:
+            field = self._field_desc(den_masks)
+            self._zero_rode = False
+            shade, keep = self._shade_desc(app_masks, enc_mask, dev, train=save_valid, zero=ws.zero_block)
+            if not self._zero_rode:      # no weight copy was due (inference with unchanged weights): zero on its own
+                ws.zero_block.zero_()
         st = _stream()
-        if not self._zero_rode:      # no weight copy was due (inference with unchanged weights): zero on its own
-            ws.zero_block.zero_()
 
         io = H.TfMarchIO()
         io.rays, io.n_rays, io.n_samples, io.ndc = rays.data_ptr(), R, N, int(bool(ndc_ray))

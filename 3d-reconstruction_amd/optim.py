@@ -133,17 +133,34 @@ class FusedAdam(torch.optim.Optimizer):
                 chunk0 += run
                 self._jobs.append((job, part, [p.data_ptr() for _, p in part]))
         for job, part, ptrs in self._jobs:
-            for i, (gi, p) in enumerate(part):
-                g = p.grad
-                if not _dense_like(p, g):
-                    raise H.HipError("FusedAdam: a gradient is not laid out like its parameter (expected the HIP "
-                                     "backward's gradient views)")
-                if p.data_ptr() != ptrs[i]:
-                    raise H.HipError("FusedAdam: a parameter's storage was replaced; build a new optimizer")
-                job.seg[i].g = g.data_ptr()
+            # the HIP backward hands out views of ONE buffer with a fixed layout: when the first and the last gradient sit
+            # where they sat relative to each other last step, every gradient does, and only the base moved
+            g0, g1, gm = part[0][1].grad, part[-1][1].grad, part[len(part) // 2][1].grad
+            if g0 is None or g1 is None or gm is None:
+                raise H.HipError("FusedAdam: a parameter lost its gradient between steps")
+            base = g0.data_ptr()
+            span = (g1.data_ptr() - base, gm.data_ptr() - base)
+            memo = getattr(job, "_memo", None)
+            if memo is not None and memo[1] == span and g0.stride() == memo[2] and g1.stride() == memo[3]:
+                if base != memo[0]:
+                    delta = base - memo[0]
+                    for i in range(len(part)):
+                        job.seg[i].g = job.seg[i].g + delta
+                    job._memo = (base, span, memo[2], memo[3])
+            else:
+                for i, (gi, p) in enumerate(part):
+                    g = p.grad
+                    if not _dense_like(p, g):
+                        raise H.HipError("FusedAdam: a gradient is not laid out like its parameter (expected the HIP "
+                                         "backward's gradient views)")
+                    if p.data_ptr() != ptrs[i]:
+                        raise H.HipError("FusedAdam: a parameter's storage was replaced; build a new optimizer")
+                    job.seg[i].g = g.data_ptr()
+                job._memo = (base, span, g0.stride(), g1.stride()) if len(part) > 1 else None
             H.check(lib.tf_adam_step(C.byref(job), st), "tf_adam_step")
         if not one_launch:
             self._step_dev += 1
-        for _, p in ps:      # the kernel wrote the parameters behind autograd's back: caches keyed on ._version
-            torch.autograd.graph.increment_version(p)       # (packed weight copies, field.py) must see the change
+        # the kernel wrote the parameters behind autograd's back: caches keyed on ._version (packed weight copies,
+        # field.py) must see the change
+        torch.autograd.graph.increment_version([p for _, p in ps])
         return loss
