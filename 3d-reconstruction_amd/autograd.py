@@ -138,27 +138,40 @@ class _RenderFn(torch.autograd.Function):
         for p, v in zip(ctx.params, ctx.versions):
             if p._version != v:
                 raise RuntimeError("a parameter was modified in place between forward and backward")
-        lib = H.lib()
-        ws = c['ws']
-        st = _stream()
         named = list(zip(names, ctx.params))
-        binned = ws.binned_cfg is not None
-        n_rep = 0 if binned else N_REP
-        presorted = c.get('sorted_on') is not None
-        if presorted:       # made on the second stream during the forward (_early_sort); usable after the join below
-            grads, flat, offs, grad_len, line_len = ctx.early_bufs
-            ctx.early_bufs = None
+        if g_rgb is None:
+            g_rgb = torch.zeros(c['ws'].R, 3, dtype=torch.float32, device=ctx.params[0].device)
+        early, ctx.early_bufs = ctx.early_bufs, None
+        grads = backward_launches(model, c, named, g_rgb, early, "all")
+        out = tuple(grads[n] if p.requires_grad else None for n, p in named)
+        ctx.c = None
+        return (None,) * 8 + out
+
+
+def backward_launches(model, c, named, g_rgb, early_bufs=None, stage="all"):
+    """The backward's kernel launches for the forward context `c` (TensorBase._run_forward(save_valid=True)).
+    stage "all": everything (autograd path).  The data-parallel graphed step cuts it in two so that the exchange of the
+    density gradients can run beside the shading backward (graph.py):
+      "density": gradient buffer, tf_march_backward, density scatter  -> the density factors' gradients are final;
+      "shade"  : tf_shade_backward, appearance scatter                -> everything else.
+    Returns {parameter name: gradient view} (views of ONE zero-filled buffer, model.grad_flat)."""
+    lib = H.lib()
+    ws = c['ws']
+    st = _stream()
+    binned = ws.binned_cfg is not None
+    n_rep = 0 if binned else N_REP
+    presorted = c.get('sorted_on') is not None
+    cp = model._is_cp()
+    if stage in ("all", "density"):
+        if presorted and early_bufs is not None:   # made on the second stream during the forward (_early_sort)
+            grads, flat, offs, grad_len, line_len = early_bufs
         else:
             grads, flat, offs, grad_len, line_len = _grad_buffers(named, n_rep)
         model.grad_flat = flat[:grad_len]   # every gradient of this step, one contiguous buffer (parallel.py)
-        if getattr(model, "grad_layout", None) is None or model.grad_layout[0] != offs:
+        if getattr(model, "grad_layout", None) is None or model.grad_layout[0] is not offs:
             model.grad_layout = (offs, grad_len)     # name -> offset (floats): parallel.gradient_support
-        if g_rgb is None:
-            g_rgb = torch.zeros(ws.R, 3, dtype=torch.float32, device=ctx.params[0].device)
         g = g_rgb.detach().to(torch.float32).contiguous()
-        cp = model._is_cp()
         rep0 = flat.data_ptr() + 4 * (grad_len if n_rep else 0)   # replica 0 of the line block (binned: the head itself)
-
         dg = H.TfFactorGrads()
         ag = H.TfFactorGrads()
         for fg, kind in ((dg, 'density'), (ag, 'app')):
@@ -167,10 +180,7 @@ class _RenderFn(torch.autograd.Function):
                 if not cp:
                     fg.plane[i] = grads[f'{kind}_plane.{i}'].data_ptr()
                 fg.line[i] = rep0 + 4 * offs[f'{kind}_line.{i}']
-        def bin_job(factors, fgrads, grad, grad_ld, part):
-            j = _bin_job(model, ws, part, factors, c['field'].grid, 2 if presorted else 0, fgrads, grad, grad_ld)
-            model._timed("tf_binned_scatter_" + part, lib.tf_binned_scatter, C.byref(j), st)
-
+        c['_bwd'] = (grads, flat, offs, grad_len, line_len, rep0, dg, ag, g)
         model._timed("tf_march_backward", lib.tf_march_backward, C.byref(c['field']), C.byref(c['io']), g.data_ptr(),
                      ws.rgb_pre.data_ptr(), int(c['use_bg']), ws.rgb.data_ptr(), ws.grad_rgb.data_ptr(), C.byref(dg),
                      ws.ent_xyz.data_ptr() if binned else None, ws.ent_df.data_ptr() if binned else None, st)
@@ -178,28 +188,35 @@ class _RenderFn(torch.autograd.Function):
             if presorted:       # join the second stream (one cross-stream wait costs ~8 us of launch latency, so
                 # there is only this one: both sorts have long finished when march_backward ends)
                 torch.cuda.current_stream().wait_stream(c['sorted_on'])
-            bin_job(c['field'].density, dg, ws.ent_df, 0, "density")
-        sg = H.TfShadeGrads()
-        sg.w1, sg.b1 = grads['renderModule.mlp.0.weight'].data_ptr(), grads['renderModule.mlp.0.bias'].data_ptr()
-        sg.w2, sg.b2 = grads['renderModule.mlp.2.weight'].data_ptr(), grads['renderModule.mlp.2.bias'].data_ptr()
-        sg.w3, sg.b3 = grads['renderModule.mlp.4.weight'].data_ptr(), grads['renderModule.mlp.4.bias'].data_ptr()
-        sg.basis = grads['basis_mat.weight'].data_ptr()
-        sg.app = ag
-        sg.dv_out, sg.wslab = ws.dv.data_ptr(), ws.wslab.data_ptr()
-        sg.x_saved, sg.rgb_fwd = ws.xs.data_ptr(), ws.rgb.data_ptr()
-        sg.h1_saved, sg.h2_saved = ws.h1s.data_ptr(), ws.h2s.data_ptr()
-        sg.direct_scatter = 0 if binned else 1
-        model._timed("tf_shade_backward", lib.tf_shade_backward, C.byref(c['shade']), c['rays'].data_ptr(),
-                     int(c['ndc']), ws.counters.data_ptr(), ws.seg_cap, ws.app_ray.data_ptr(), ws.app_xyz.data_ptr(),
-                     ws.grad_rgb.data_ptr(), C.byref(sg), st)
-        if binned:
-            bin_job(c['shade'].app, ag, ws.dv, model._n_app_total(), "app")
-        if n_rep:
-            model._timed("tf_reduce_replicas", lib.tf_reduce_replicas, rep0, n_rep, line_len, line_len, flat.data_ptr(), st)
-        out = tuple(grads[n] if p.requires_grad else None for n, p in named)
-        ws.busy, ws.owner = False, None     # stream order: the next forward that takes this workspace runs after these kernels
-        ctx.c = None
-        return (None,) * 8 + out
+            j = _bin_job(model, ws, "density", c['field'].density, c['field'].grid, 2 if presorted else 0, dg, ws.ent_df, 0)
+            model._timed("tf_binned_scatter_density", lib.tf_binned_scatter, C.byref(j), st)
+        hook = getattr(model, "_density_grads_ready", None)
+        if hook is not None and binned:     # eager data parallel: the density gradients can travel now (parallel.py)
+            hook(model)
+        if stage == "density":
+            return grads
+    grads, flat, offs, grad_len, line_len, rep0, dg, ag, g = c['_bwd']
+    sg = H.TfShadeGrads()
+    sg.w1, sg.b1 = grads['renderModule.mlp.0.weight'].data_ptr(), grads['renderModule.mlp.0.bias'].data_ptr()
+    sg.w2, sg.b2 = grads['renderModule.mlp.2.weight'].data_ptr(), grads['renderModule.mlp.2.bias'].data_ptr()
+    sg.w3, sg.b3 = grads['renderModule.mlp.4.weight'].data_ptr(), grads['renderModule.mlp.4.bias'].data_ptr()
+    sg.basis = grads['basis_mat.weight'].data_ptr()
+    sg.app = ag
+    sg.dv_out, sg.wslab = ws.dv.data_ptr(), ws.wslab.data_ptr()
+    sg.x_saved, sg.rgb_fwd = ws.xs.data_ptr(), ws.rgb.data_ptr()
+    sg.h1_saved, sg.h2_saved = ws.h1s.data_ptr(), ws.h2s.data_ptr()
+    sg.direct_scatter = 0 if binned else 1
+    model._timed("tf_shade_backward", lib.tf_shade_backward, C.byref(c['shade']), c['rays'].data_ptr(),
+                 int(c['ndc']), ws.counters.data_ptr(), ws.seg_cap, ws.app_ray.data_ptr(), ws.app_xyz.data_ptr(),
+                 ws.grad_rgb.data_ptr(), C.byref(sg), st)
+    if binned:
+        j = _bin_job(model, ws, "app", c['shade'].app, c['field'].grid, 2 if presorted else 0, ag, ws.dv, model._n_app_total())
+        model._timed("tf_binned_scatter_app", lib.tf_binned_scatter, C.byref(j), st)
+    if n_rep:
+        model._timed("tf_reduce_replicas", lib.tf_reduce_replicas, rep0, n_rep, line_len, line_len, flat.data_ptr(), st)
+    ws.busy, ws.owner = False, None     # stream order: the next forward that takes this workspace runs after these kernels
+    c.pop('_bwd', None)
+    return grads
 
 
 def render_with_grad(model, rays, mask, white_bg, is_train, ndc_ray, N_samples):

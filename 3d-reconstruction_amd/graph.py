@@ -8,9 +8,10 @@ device (sample counts, packed lists, bins), so the captured launch sequence is s
 step is: draw the stratified jitter from the CPU generator exactly like the reference (tensorBase.py:201),
 stage the batch into the static input buffers, replay.
 
-Data parallel (`world_size > 1`): the step is captured as TWO graphs — forward/loss/backward and the optimizer
-step — with the one gradient all-reduce (`parallel.allreduce_gradients`, RCCL) issued eagerly between the two
-replays on the same stream, so no collective is ever inside a capture.
+Data parallel (`world_size > 1`): the step is captured as THREE graphs — (a) forward / loss / backward up to the density
+gradients, (b) shading backward + appearance scatter, (c) regularisers + optimizer — with the gradient exchange
+(`parallel.exchange_begin / exchange_end`, RCCL) issued eagerly in two buckets between the replays: the density bucket
+travels while (b) replays, so no collective is ever inside a capture and only the second bucket is exposed.
 
 When the schedule replaces the alpha mask or the parameters (updateAlphaMask, shrink, upsample_volume_grid — the
 caller then assigns the rebuilt optimizer to `.opt`, as train.py:300-311 rebuilds it), the next `step` notices,
@@ -112,6 +113,41 @@ class GraphedTrainStep:
             self._regw.copy_(torch.tensor(vals).pin_memory(), non_blocking=True)
             self._regw_host = vals
 
+    # ---- data-parallel pieces (no autograd: the launches are issued directly, so the backward can be cut in two) -----
+    def _named(self):
+        named = list(self.model.named_parameters())
+        return named
+
+    def _fwd_density(self):
+        """forward + loss gradient + the backward up to the point where the density gradients are final"""
+        from .autograd import _early_sort, backward_launches
+        model = self.model
+        named = self._named()
+        keep, model.count_samples = model.count_samples, False
+        hook, model._density_grads_ready = getattr(model, "_density_grads_ready", None), None   # no collective in a capture
+        try:
+            with torch.no_grad():
+                c = model._run_forward(self.rays, self.mask, self.white_bg, True, self.ndc, self.n_samples, save_valid=True,
+                                       after_march=lambda ws, field, shade: _early_sort(model, ws, field, shade, named))
+            early = None
+            if c.get('sorted_on') is not None:
+                c['sorted_on'], early = c['sorted_on']
+            rgb = c['rgb_map']
+            H.check(H.lib().tf_mse_grad(rgb.data_ptr(), self.target.data_ptr(), rgb.numel(), 1.0 / self._world,
+                                        self.loss.data_ptr(), self._grad_rgb.data_ptr(), _stream()), "tf_mse_grad")
+            grads = backward_launches(model, c, named, self._grad_rgb, early, "density")
+        finally:
+            model.count_samples = keep
+            model._density_grads_ready = hook
+        for n, p in named:
+            p.grad = grads[n]
+        self._ctx = (c, named)
+
+    def _shade_half(self):
+        from .autograd import backward_launches
+        c, named = self._ctx
+        backward_launches(self.model, c, named, self._grad_rgb, None, "shade")
+
     def _regs_and_opt(self):
         if self._regw is not None:      # rank-invariant terms: added after the data gradients have been reduced
             from .regularizers import add_regularizer_grads_
@@ -119,9 +155,15 @@ class GraphedTrainStep:
         self.opt.step()
 
     def _body(self):
-        self._fwd_bwd()
-        if self.split:
-            parallel.allreduce_gradients(self.model, average=False)
+        if self.split:      # the eager warm-up runs the very sequence the three graphs will replay
+            self._fwd_density()
+            pend_d = parallel.exchange_begin(self.model, "density")
+            self._shade_half()
+            pend_r = parallel.exchange_begin(self.model, "rest")
+            parallel.exchange_end(self.model, pend_d, average=False)
+            parallel.exchange_end(self.model, pend_r, average=False)
+        else:
+            self._fwd_bwd()
         self._regs_and_opt()
 
     def _stage(self, rays, target, ids=None):
@@ -163,10 +205,10 @@ class GraphedTrainStep:
             self._warm = 1
         hit = self._graphs.get(self._bg)
         if hit is not None:
-            hit[0].replay()
-            if self.split:
-                parallel.allreduce_gradients(self.model, average=False)      # on model.grad_flat: a static buffer of the graph's pool
-                hit[1].replay()
+            if not self.split:
+                hit[0].replay()
+            else:
+                self._replay_split(hit)
             self._after_replay()
             return self.loss
         self.model.static_jitter = self.jitter
@@ -201,20 +243,35 @@ class GraphedTrainStep:
             g.replay()                                            # capture only records; run this step now
             self._after_replay()
             return self.loss
-        # thread-local capture mode: the process group's helper threads (RCCL proxy / watchdog, gloo workers) may
-        # make HIP calls of their own while this thread captures; they never touch the captured stream
+        # Three graphs: (a) forward + loss + backward until the density gradients are final, (b) shading backward +
+        # appearance scatter, (c) regularisers + Adam — with the two buckets of the gradient exchange issued eagerly in
+        # between, the density bucket travelling while (b) replays.  Thread-local capture mode: the process group's
+        # helper threads (RCCL proxy / watchdog, gloo workers) may make HIP calls of their own while this thread
+        # captures; they never touch the captured stream.
         with torch.cuda.graph(g, stream=self._side, pool=pool, capture_error_mode="thread_local"):
-            self._fwd_bwd()
+            self._fwd_density()
+        gb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gb, stream=self._side, pool=g.pool(), capture_error_mode="thread_local"):
+            self._shade_half()
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2, stream=self._side, pool=g.pool(), capture_error_mode="thread_local"):
             self._regs_and_opt()
-        self._graphs[self._bg] = (g, g2)
+        self._graphs[self._bg] = (g, g2, gb)
         self.graph, self.graph_opt = g, g2
-        g.replay()
-        parallel.allreduce_gradients(self.model, average=False)
-        g2.replay()
+        self._replay_split(self._graphs[self._bg])
         self._after_replay()
         return self.loss
+
+    def _replay_split(self, graphs):
+        ga, gopt, gb = graphs
+        model = self.model
+        ga.replay()
+        pend_d = parallel.exchange_begin(model, "density")      # on model.grad_flat: a static buffer of the graph's pool
+        gb.replay()                                             # ... beside the density bucket's collective
+        pend_r = parallel.exchange_begin(model, "rest")
+        parallel.exchange_end(model, pend_d, average=False)     # (gradients are pre-divided by the world size)
+        parallel.exchange_end(model, pend_r, average=False)
+        gopt.replay()
 
     def _after_replay(self):
         """A replay runs Adam behind autograd's back: the parameters' `_version` counters (bumped once, at capture) no

@@ -95,6 +95,10 @@ def train(tensorf, allrays, allrgbs, cfg=None, device="cuda", rank=0, world=1, l
         allrays, allrgbs = allrays.to(device).float().contiguous(), allrgbs.to(device).float().contiguous()
         gs = GraphedTrainStep(tensorf, opt, batch, nSamples, ndc_ray=c["ndc_ray"], white_bg=c["white_bg"], warmup=1,
                               regularizers=True)
+    if c.get("fused_regularizers", True) and fused_supported(tensorf) and gs is None:
+        # eager data parallel: the density gradients leave during the backward (only where nothing else touches .grad
+        # before the exchange: the autograd regularisers of the other branch accumulate into it asynchronously)
+        parallel.enable_overlapped_exchange(tensorf)
     gc.collect()
     gc.freeze()
     mask = None
@@ -124,7 +128,7 @@ def train(tensorf, allrays, allrgbs, cfg=None, device="cuda", rank=0, world=1, l
                 # rays, so their gradient is added after the data gradients have been reduced across ranks
                 opt.zero_grad()
                 loss.backward()
-                parallel.allreduce_gradients(tensorf)
+                parallel.finish_gradient_exchange(tensorf)
                 if max(use_ortho, l1_w, tv_d, tv_a) > 0:
                     add_regularizer_grads_(tensorf, use_ortho, l1_w, max(tv_d, 0.0), max(tv_a, 0.0))
             else:

@@ -236,6 +236,21 @@ def dry_run(args, world, rank, backend):
         dist.destroy_process_group()
 
 
+class _stdout_to_stderr:
+    """RCCL prints a version banner on stdout when its first communicator comes up; the contract is ONE JSON line on
+    stdout, so file descriptor 1 points at stderr while the process group initialises and runs its first collective."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -259,10 +274,14 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
+        with _stdout_to_stderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group(backend)
+            warm = torch.zeros(1, device=torch.device("cuda", local))
+            dist.all_reduce(warm)                 # brings the communicator up (and its banner out) now
+            torch.cuda.synchronize()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -294,6 +313,7 @@ def main():
     opt = make_opt(use_graph)
     graphed = recon_amd.GraphedTrainStep(model, opt, B, n_samples) if use_graph else None
     model.lazy_sample_count = True   # the renderer's 6th return value syncs only when read (train.py never reads it)
+    parallel.enable_overlapped_exchange(model)
     renderer = recon_amd.OctreeRender_trilinear_fast
 
     def train_step(i):
@@ -304,7 +324,7 @@ def main():
         loss = torch.mean((rgb_map - rgb_train) ** 2)
         opt.zero_grad()
         loss.backward()
-        parallel.allreduce_gradients(model)
+        parallel.finish_gradient_exchange(model)      # (its density bucket left during the backward)
         opt.step()
         return loss
 
