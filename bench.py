@@ -261,6 +261,10 @@ def main():
         sys.exit(2)
     if args.dry_run:
         return dry_run(args, world, int(os.environ.get("RANK", "0")), os.environ.get("TF_DIST_BACKEND", "nccl"))
+    # everything but the final JSON line goes to stderr: the library under test prints progress lines like the reference
+    # does (alpha-mask statistics, "grid resized ..."), RCCL prints a banner, and the contract is ONE line on stdout
+    guard = _stdout_to_stderr()
+    guard.__enter__()
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # TF_DIST_BACKEND=gloo rehearses the N>1 code path with several ranks sharing one GPU (RCCL refuses that);
@@ -499,7 +503,12 @@ def main():
             # alpha-mask update and one grid up-sampling inside the run (tests/psnr_parity.py; ~35 s, mostly the eager side)
             from tests import psnr_parity
             line["psnr"] = psnr_parity.run(recon_amd, dev=str(dev), grid=64, iters=600, schedule=True, init_grid=48)
+        guard.__exit__()
+        guard = None
         print(json.dumps(line))
+        sys.stdout.flush()
+    if guard is not None:
+        guard.__exit__()
     if dist.is_initialized():
         dist.destroy_process_group()
 
