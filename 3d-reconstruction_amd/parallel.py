@@ -275,6 +275,8 @@ def exchange_begin(model, part, group=None):
     exchange_end needs.  With an alpha mask only the cells that can be non-zero travel (row gather -> all-reduce ->
     row write-back, as in allreduce_gradients).  The collective is asynchronous: with RCCL it runs on the process
     group's stream, ordered behind the kernels enqueued so far and beside those enqueued next."""
+    if not dist.is_available() or not dist.is_initialized():      # no process group: a one-process run, nothing travels
+        return []
     flat = model.grad_flat
     br = _bucket_rows(model)
     pending = []
@@ -298,6 +300,8 @@ def exchange_begin(model, part, group=None):
 
 def exchange_end(model, pending, average=True, group=None):
     """Waits for the bucket (the compute stream waits, not the host, under RCCL) and writes gathered rows back."""
+    if not pending:
+        return
     world = dist.get_world_size(group)
     flat = model.grad_flat
     for work, buf, idx, w in pending:

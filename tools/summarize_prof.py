@@ -13,7 +13,7 @@ import sys
 
 
 def _ours(name):
-    return any(k in name for k in ("march_", "shade_", "composite_kernel", "reduce_replicas", "pack_", "bin_", "adam_kernel",
+    return any(k in name for k in ("march_", "shade_", "composite_kernel", "reduce_replicas", "pack_", "bin_", "tile_", "adam_kernel",
                                    "wslab_"))
 
 
