@@ -238,9 +238,12 @@ __device__ __forceinline__ void pe_block(float* X, int sx, int off, int D, int F
         float fr = 1.f;
         int k = 0;
         for (; k + 1 < F; k += 2) {
-            float s0, c0, s1, c1;
+            // the odd frequency of a pair by the double-angle identities: sin 2a = 2 sin a cos a, cos 2a = 1 - 2 sin^2 a
+            // (|error| <= 2 x the 1.5-ulp error of the pair's first evaluation + 1 rounding: < 4e-7 absolute) — half the
+            // range reductions and polynomials of the block
+            float s0, c0;
             pe_sincos_fast(v * fr, &s0, &c0);
-            pe_sincos_fast(v * (fr * 2.f), &s1, &c1);
+            float s1 = (2.f * s0) * c0, c1 = fmaf(-2.f * s0, s0, 1.f);
             const int ci = d * F + k;
             if (mk && on) {
                 s0 *= mk[ci];
