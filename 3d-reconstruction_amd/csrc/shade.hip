@@ -169,7 +169,7 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
             const int smp = (tid >> 6) * 8 + (lane >> 3), sub = lane & 7;
             float u[3] = {ixyz[smp * 3], ixyz[smp * 3 + 1], ixyz[smp * 3 + 2]};
             float* vrow = regA + smp * L.sv;
-            app_products(S, u, sub, vrow, 8);
+            if (!app_products_lanes8(S, u, sub, vrow)) app_products(S, u, sub, vrow, 8);
             for (int c = S.n_app_total + sub; c < kpad16(S.n_app_total); c += 8) vrow[c] = 0.f;
         }
         __syncthreads();

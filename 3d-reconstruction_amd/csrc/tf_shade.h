@@ -203,6 +203,59 @@ __device__ __forceinline__ void app_products(const TfShade& S, const float u[3],
     }
 }
 
+// The same products for TensorVMSplit fields read by EIGHT lanes per sample (shade_forward's gather), components a
+// multiple of 4 and at most 64 per plane: a lane takes channel quads s, s + 8 of a plane and requests all (<= 12) tap
+// pieces of the plane / line pair before it uses the first — the per-quad loop above waits out one round trip per quad.
+// Which half of the lanes takes the second quad alternates from plane to plane (48 components = 12 quads on 8 lanes: 5 / 4
+// quads per lane over the three planes instead of 6 / 3).  Returns false (nothing written) for other shapes.
+__device__ __forceinline__ bool app_products_lanes8(const TfShade& S, const float u[3], int sub, float* vrow) {
+    if (S.model != TF_MODEL_VM) return false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if ((S.app.n_comp[i] & 3) != 0 || S.app.n_comp[i] > 64) return false;
+    VmTaps t;
+    make_vm_taps(S.grid, u, t);
+    int coff = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int C = S.app.n_comp[i], Q = C >> 2;
+        const float* mk = S.app.mask[i];
+        const int s2 = (sub + 4 * (i & 1)) & 7;
+        const bool has0 = s2 < Q, has1 = s2 + 8 < Q;
+        const int q[2] = {has0 ? s2 : 0, has1 ? s2 + 8 : (has0 ? s2 : 0)};      // (lanes without a quad re-read one: no branch)
+        float4_t pa[2][4], la[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ch = q[j] * 4;
+            pa[j][0] = ld4(S.app.plane[i] + (size_t)t.p[i].o00 * C + ch);
+            pa[j][1] = ld4(S.app.plane[i] + (size_t)t.p[i].o01 * C + ch);
+            pa[j][2] = ld4(S.app.plane[i] + (size_t)t.p[i].o10 * C + ch);
+            pa[j][3] = ld4(S.app.plane[i] + (size_t)t.p[i].o11 * C + ch);
+            la[j][0] = ld4(S.app.line[i] + (size_t)t.l[i].o0 * C + ch);
+            la[j][1] = ld4(S.app.line[i] + (size_t)t.l[i].o1 * C + ch);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (j == 0 ? !has0 : !has1) continue;
+            const int ch = q[j] * 4;
+            float4_t p, l;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                p[k] = fmaf(pa[j][3][k], t.p[i].w11, fmaf(pa[j][2][k], t.p[i].w10, fmaf(pa[j][1][k], t.p[i].w01, pa[j][0][k] * t.p[i].w00)));
+                l[k] = fmaf(la[j][1][k], t.l[i].w1, la[j][0][k] * t.l[i].w0);
+            }
+            if (mk) {
+                const float4_t m = ld4(mk + ch);
+                p *= m;
+                l *= m;
+            }
+            *reinterpret_cast<float4_t*>(vrow + coff + ch) = p * l;
+        }
+        coff += C;
+    }
+    return true;
+}
+
 // One positional-encoding block of a 64-sample tile written into X (mlp.py:8-13): for every (sample, dim) the F
 // frequencies v*2^k -> sin at x[off + d*F + k], cos at x[off + D*F + d*F + k], times the optional masks.
 // `val(smp, d)` supplies v.  NT threads cooperate.  The F evaluations of an item are independent and evaluated

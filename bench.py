@@ -473,6 +473,21 @@ def main():
             "kernels": {n: {"avg_ms": round(v["avg_ms"], 5), "GBps": round(v["GBps"], 1),
                             "TFLOPps": round(v["TFLOPps"], 2)} for n, v in kt.items()},
         }
+        if args.mode == "train" and world == 1:
+            # the eval half of BASELINE's metric (the renderer forward on the same batches), so that the driver's default run
+            # records it too: `python bench.py --mode eval` reports the same measurement as a line of its own
+            for i in range(5):
+                eval_step(i)
+            torch.cuda.synchronize()
+            te = time.perf_counter()
+            n_ev = max(args.steps, 20)
+            for i in range(n_ev):
+                eval_step(i % n_steps)
+            torch.cuda.synchronize()
+            t_ev = (time.perf_counter() - te) / n_ev
+            line["eval"] = {"metric": f"rays/sec (eval), Lego 800^2 @ {args.grid}^3 grid", "value": B / t_ev, "unit": "rays/s",
+                            "ms_per_step": t_ev * 1e3, "steps": n_ev,
+                            "note": "renderer forward (OctreeRender_trilinear_fast, is_train=False) on the same 4096-ray batches, eager launches"}
         if not args.no_baselines and world == 1:
             cores = os.cpu_count()
             # thread-count sweep: one thread per core oversubscribes a 100+-core host on this memory-bound eager path
