@@ -589,13 +589,13 @@ static int launch_sort(const TfBinJob* const jobs[2], int n, hipStream_t st) {
         A.csh[1] = A.csh[0];
     }
     const size_t lds = sizeof(int) * (size_t)kr;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(bin_count_kernel), (size_t)(lds));
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(bin_count_kernel, dim3(n * kSortWgs), dim3(kSortThreads), lds, st, A);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = ensure_dynamic_lds(reinterpret_cast<const void*>(bin_scan_kernel), (size_t)(lds));
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(bin_scan_kernel, dim3(n), dim3(1024), lds, st, A);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = ensure_dynamic_lds(reinterpret_cast<const void*>(bin_fill_kernel), (size_t)(lds));
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(bin_fill_kernel, dim3(n * kSortWgs), dim3(kSortThreads), lds, st, A);
     return TF_CHECK_LAUNCH();
@@ -628,8 +628,7 @@ int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream) {
         if (rc != 0 || job->stage == 1) return rc;
     }
     if (!job->grad) return (int)hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)sc_bytes);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(bin_scatter_kernel), (size_t)(sc_bytes));
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(256 * per_cu), dim3(256), sc_bytes, st, *job, K, ER, cmax);
     return TF_CHECK_LAUNCH();

@@ -286,8 +286,7 @@ int tf_march_backward(const TfField* field, const TfMarchIO* io, const float* gr
     const size_t lds = (size_t)ncap * 12 + (field->model == TF_MODEL_VM ? (size_t)chunk_lds_words(ctot) * 4 : 0);
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
     BwdArgs B{grad_rgb_map, rgb_pre, rgb, grad_rgb, white_bg, ent_xyz, ent_df};
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(march_backward_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(march_backward_kernel), (size_t)(lds));
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(march_backward_kernel, dim3(io->n_rays), dim3(64), lds, (hipStream_t)stream, *field, *io, B,
                        *dgrads);

@@ -407,7 +407,7 @@ int launch_shade(const TfShade* S, const TileSrc& src, float* rgb_out, float* fe
     const ShadeLds L = shade_lds(*S);
     const size_t bytes = (size_t)L.total * sizeof(float);
     if (bytes > 160 * 1024 - 1024) return (int)hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(fn), (size_t)(bytes));
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(512), bytes, st, *S, src, rgb_out, feat_out, save);
     return TF_CHECK_LAUNCH();

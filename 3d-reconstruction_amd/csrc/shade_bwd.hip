@@ -806,7 +806,7 @@ int tf_shade_backward(const TfShade* shade, const float* rays, int ndc, const in
     if (!fn) return (int)hipErrorInvalidValue;   // head / width outside the trained configurations
     const BwdLds L = bwd_lds(*shade);
     const size_t bytes = (size_t)L.total * sizeof(float);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(fn), (size_t)(bytes));
     if (e != hipSuccess) return (int)e;
     if (!grads->dv_out || !grads->wslab || !grads->x_saved || !grads->rgb_fwd || !shade->w1t || !shade->w2t)
         return (int)hipErrorInvalidValue;

@@ -14,6 +14,28 @@
 
 namespace tf {
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and size: the attribute is a ceiling, so a launch needs
+// the call only when it asks for more than any launch before it (the eager training step made 11 of these calls per step,
+// each a few microseconds of host time on a host-bound path).  Host code runs on the caller's single thread.
+inline hipError_t ensure_dynamic_lds(const void* fn, size_t bytes) {
+    static const void* seen_fn[64];
+    static size_t seen_bytes[64];
+    static int n_seen = 0;
+    for (int i = 0; i < n_seen; ++i)
+        if (seen_fn[i] == fn) {
+            if (bytes <= seen_bytes[i]) return hipSuccess;
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e == hipSuccess) seen_bytes[i] = bytes;
+            return e;
+        }
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && n_seen < 64) {
+        seen_fn[n_seen] = fn;
+        seen_bytes[n_seen++] = bytes;
+    }
+    return e;
+}
+
 // Diagnostic build only (-DTF_PHASE_TIMING): switches to ablate the atomic traffic (bit 0: skip plane
 // atomics, bit 1: skip line atomics).  Compiled out of the shipped library.
 #ifdef TF_PHASE_TIMING
