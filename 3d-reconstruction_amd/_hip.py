@@ -84,6 +84,10 @@ class TfBinJob(C.Structure):
                 ("items_cap", C.c_int), ("status", _fp)]
 
 
+class TfLossFuse(C.Structure):
+    _fields_ = [("target", _fp), ("grad_scale", C.c_float), ("grad", _fp), ("loss", _fp), ("state", _fp)]
+
+
 class TfCamera(C.Structure):
     _fields_ = [("height", C.c_int), ("width", C.c_int), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
                 ("cy", C.c_float), ("c2w", C.c_float * 12), ("opengl", C.c_int), ("normalize", C.c_int), ("ndc", C.c_int),
@@ -141,6 +145,7 @@ _SIGS = {
     "tf_march_forward": [C.POINTER(TfField), C.POINTER(TfMarchIO), _fp],
     "tf_shade_forward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, C.c_int, C.POINTER(TfShadeSave), _fp],
     "tf_composite_forward": [C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp, _fp, _fp],
+    "tf_composite_forward_loss": [C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp, _fp, C.POINTER(TfLossFuse), _fp],
     "tf_density_points": [C.POINTER(TfField), _fp, C.c_int, _fp, _fp],
     "tf_appfeature_points": [C.POINTER(TfShade), _fp, C.c_int, _fp, _fp],
     "tf_shade_points": [C.POINTER(TfShade), _fp, _fp, _fp, C.c_int, _fp, _fp],

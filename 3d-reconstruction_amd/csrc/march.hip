@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void composite_kernel(int n_rays, const int* _
                                                         int white_bg, float* __restrict__ rgb_map,
                                                         float* __restrict__ rgb_pre,
                                                         const int* __restrict__ counters,
-                                                        long long* __restrict__ n_shaded) {
+                                                        long long* __restrict__ n_shaded, const TfLossFuse L) {
     if (n_shaded && blockIdx.x == 0 && threadIdx.x == 0) {     // num_valid_samples = app_mask.sum()  (tensorBase.py:390)
         long long t = 0;
         for (int g = 0; g < kShards; ++g) t += counters[g * kShardStride];
@@ -357,11 +357,38 @@ __global__ __launch_bounds__(256) void composite_kernel(int n_rays, const int* _
         c[a] += __shfl_xor(c[a], 2, 64);
         c[a] += __shfl_xor(c[a], 4, 64);
     }
+    float d2 = 0.f;
     if (r < n_rays && sub < 3) {
         float v = sub == 0 ? c[0] : (sub == 1 ? c[1] : c[2]);
         if (white_bg) v += 1.f - acc[r];
         if (rgb_pre) rgb_pre[(size_t)r * 3 + sub] = v;
-        rgb_map[(size_t)r * 3 + sub] = fminf(fmaxf(v, 0.f), 1.f);
+        const float o = fminf(fmaxf(v, 0.f), 1.f);
+        rgb_map[(size_t)r * 3 + sub] = o;
+        if (L.target) {      // loss = mean((rgb_map - target)^2) and its gradient (train.py:334), as mse_grad_kernel
+            const float inv = 1.f / (float)(3 * n_rays);
+            const float d = o - L.target[(size_t)r * 3 + sub];
+            d2 = d * d;
+            L.grad[(size_t)r * 3 + sub] = 2.f * d * inv * L.grad_scale;
+        }
+    }
+    if (L.target) {
+        // workgroup sum -> one atomic; the last workgroup to arrive publishes the mean and re-arms the two state words
+        __shared__ float red[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d2 += __shfl_xor(d2, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d2;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(L.state, (red[0] + red[1]) + (red[2] + red[3]));
+            __threadfence();
+            unsigned* arrivals = reinterpret_cast<unsigned*>(L.state + 1);
+            if (atomicAdd(arrivals, 1u) == gridDim.x - 1) {
+                __threadfence();
+                const float total = atomicExch(L.state, 0.f);
+                *L.loss = total * (1.f / (float)(3 * n_rays));
+                *arrivals = 0u;
+            }
+        }
     }
 }
 
@@ -426,7 +453,18 @@ int tf_composite_forward(int n_rays, const int* app_offset, const int* app_count
                          const int* counters, long long* n_shaded, tf_stream_t stream) {
     if (n_rays <= 0) return 0;
     hipLaunchKernelGGL(composite_kernel, dim3((n_rays + 31) / 32), dim3(256), 0, (hipStream_t)stream, n_rays,
-                       app_offset, app_count, app_w, rgb, acc, white_bg, rgb_map, rgb_pre, counters, n_shaded);
+                       app_offset, app_count, app_w, rgb, acc, white_bg, rgb_map, rgb_pre, counters, n_shaded,
+                       TfLossFuse{nullptr, 0.f, nullptr, nullptr, nullptr});
+    return TF_CHECK_LAUNCH();
+}
+
+int tf_composite_forward_loss(int n_rays, const int* app_offset, const int* app_count, const float* app_w,
+                              const float* rgb, const float* acc, int white_bg, float* rgb_map, float* rgb_pre,
+                              const int* counters, long long* n_shaded, const TfLossFuse* fuse, tf_stream_t stream) {
+    if (n_rays <= 0) return 0;
+    if (!fuse || !fuse->target || !fuse->grad || !fuse->loss || !fuse->state) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(composite_kernel, dim3((n_rays + 31) / 32), dim3(256), 0, (hipStream_t)stream, n_rays,
+                       app_offset, app_count, app_w, rgb, acc, white_bg, rgb_map, rgb_pre, counters, n_shaded, *fuse);
     return TF_CHECK_LAUNCH();
 }
 

@@ -275,6 +275,7 @@ class TensorBase(nn.Module):
         self.bin_tile, self.bin_bucket, self.bin_chunk = 8, 8, 512
         self._jitter_override = None   # tests: inject the stratified jitter instead of drawing it
         self._bg_override = None       # GraphedTrainStep: outcome of the random-background draw of tensorBase.py:380
+        self._loss_fuse = None         # GraphedTrainStep: TfLossFuse — the compositing launch also forms the loss and its gradient
         self.static_jitter = None      # graph capture: device tensor (R,) the harness refills before every replay
         self._debug_masks = False      # tests: also emit the bbox / valid bitmaps
         self._ws_cache = {}
@@ -779,10 +780,16 @@ class TensorBase(nn.Module):
                     ws.counters.data_ptr(), ws.seg_cap, ws.app_ray.data_ptr(), ws.app_xyz.data_ptr(),
                     ws.rgb.data_ptr(), self.shade_wgs_beside_sort if sorted_on is not None else 0,
                     C.byref(save) if save is not None else None, st)
-        self._timed("tf_composite_forward", lib.tf_composite_forward, R, ws.app_offset.data_ptr(),
-                    ws.app_count.data_ptr(), ws.app_w.data_ptr(), ws.rgb.data_ptr(), ws.acc.data_ptr(), int(use_bg),
-                    out_rgb.data_ptr(), ws.rgb_pre.data_ptr() if save_valid else None, ws.counters.data_ptr(),
-                    H.ptr(out_n), st)
+        fuse = self._loss_fuse if save_valid else None     # graph.GraphedTrainStep: loss + its gradient in the same launch
+        if fuse is not None:
+            self._timed("tf_composite_forward", lib.tf_composite_forward_loss, R, ws.app_offset.data_ptr(),
+                        ws.app_count.data_ptr(), ws.app_w.data_ptr(), ws.rgb.data_ptr(), ws.acc.data_ptr(), int(use_bg),
+                        out_rgb.data_ptr(), ws.rgb_pre.data_ptr(), ws.counters.data_ptr(), H.ptr(out_n), C.byref(fuse), st)
+        else:
+            self._timed("tf_composite_forward", lib.tf_composite_forward, R, ws.app_offset.data_ptr(),
+                        ws.app_count.data_ptr(), ws.app_w.data_ptr(), ws.rgb.data_ptr(), ws.acc.data_ptr(), int(use_bg),
+                        out_rgb.data_ptr(), ws.rgb_pre.data_ptr() if save_valid else None, ws.counters.data_ptr(),
+                        H.ptr(out_n), st)
         ctx = dict(ws=ws, rgb_map=out_rgb, depth=out_depth, rays=rays, field=field, shade=shade, io=io, keep=(keep, den_masks, app_masks, jitter, ztab),
                    use_bg=use_bg, ndc=bool(ndc_ray), sorted_on=sorted_on, n_shaded=out_n)
         self.last = ctx

@@ -56,6 +56,7 @@ class GraphedTrainStep:
         self.jitter = torch.zeros(batch, device=dev)
         self.loss = torch.zeros((), device=dev)
         self._grad_rgb = torch.zeros(batch, 3, device=dev)
+        self._loss_state = torch.zeros(2, device=dev)      # tf_composite_forward_loss: running sum + arrival counter
         self.n_samples, self.mask, self.ndc = n_samples, mask, ndc_ray
         # white_bg=False (datasets without a white background, e.g. llff.py:141): the reference adds the white
         # background to a training batch with probability 1/2 (tensorBase.py:380) — a host decision per step, so the
@@ -94,17 +95,24 @@ class GraphedTrainStep:
     def _fwd_bwd(self):
         model = self.model
         keep, model.count_samples = model.count_samples, False     # nobody reads num_valid_samples here
+        # loss = mean((rgb - target)^2) (train.py:334) and d loss / d rgb are formed by the compositing launch itself
+        # (tf_composite_forward_loss): no launch of their own between the forward and the backward
+        model._loss_fuse = self._fuse(1.0 / self._world if self.split else 1.0)
         try:
             rgb, _, _ = model(self.rays, self.mask, white_bg=self.white_bg, is_train=True, ndc_ray=self.ndc,
                               N_samples=self.n_samples)
         finally:
             model.count_samples = keep
-        # loss = mean((rgb - target)^2) (train.py:334) and d loss / d rgb in one launch instead of ~8 torch kernels
-        H.check(H.lib().tf_mse_grad(rgb.data_ptr(), self.target.data_ptr(), rgb.numel(),
-                                    1.0 / self._world if self.split else 1.0, self.loss.data_ptr(),
-                                    self._grad_rgb.data_ptr(), _stream()), "tf_mse_grad")
+            model._loss_fuse = None
         self.opt.zero_grad(set_to_none=True)
         rgb.backward(self._grad_rgb)
+
+    def _fuse(self, grad_scale):
+        """TfLossFuse of this step's static buffers (target, gradient, loss, the kernel's two state words)."""
+        f = H.TfLossFuse()
+        f.target, f.grad_scale = self.target.data_ptr(), float(grad_scale)
+        f.grad, f.loss, f.state = self._grad_rgb.data_ptr(), self.loss.data_ptr(), self._loss_state.data_ptr()
+        return f
 
     def set_regularizer_weights(self, ortho=0.0, l1=0.0, tv_density=0.0, tv_app=0.0):
         """Weights of the four regulariser terms for the next step(s) (needs regularizers=True)."""
@@ -125,6 +133,7 @@ class GraphedTrainStep:
         named = self._named()
         keep, model.count_samples = model.count_samples, False
         hook, model._density_grads_ready = getattr(model, "_density_grads_ready", None), None   # no collective in a capture
+        model._loss_fuse = self._fuse(1.0 / self._world)
         try:
             with torch.no_grad():
                 c = model._run_forward(self.rays, self.mask, self.white_bg, True, self.ndc, self.n_samples, save_valid=True,
@@ -132,13 +141,11 @@ class GraphedTrainStep:
             early = None
             if c.get('sorted_on') is not None:
                 c['sorted_on'], early = c['sorted_on']
-            rgb = c['rgb_map']
-            H.check(H.lib().tf_mse_grad(rgb.data_ptr(), self.target.data_ptr(), rgb.numel(), 1.0 / self._world,
-                                        self.loss.data_ptr(), self._grad_rgb.data_ptr(), _stream()), "tf_mse_grad")
             grads = backward_launches(model, c, named, self._grad_rgb, early, "density")
         finally:
             model.count_samples = keep
             model._density_grads_ready = hook
+            model._loss_fuse = None
         for n, p in named:
             p.grad = grads[n]
         self._ctx = (c, named)

@@ -209,6 +209,21 @@ int tf_shade_forward(const TfShade* shade, const float* rays, int ndc, const int
 int tf_composite_forward(int n_rays, const int* app_offset, const int* app_count, const float* app_w,
                          const float* rgb, const float* acc, int white_bg, float* rgb_map, float* rgb_pre,
                          const int* counters, long long* n_shaded, tf_stream_t stream);
+/* The same launch followed, inside the kernel, by the photometric loss of train.py:334 and its gradient (what
+ * tf_mse_grad computes in a launch of its own): grad[i] = grad_scale * 2 (rgb_map[i] - target[i]) / (3 n_rays), and
+ * *loss = mean((rgb_map - target)^2), written once by the last workgroup to finish.  `state` = 2 device words, zero when
+ * first used; the kernel leaves them zero.  (The captured training step uses this form: one launch less on its critical
+ * path.) */
+typedef struct TfLossFuse {
+    const float* target;   /* (n_rays, 3) */
+    float grad_scale;
+    float* grad;           /* (n_rays, 3) out */
+    float* loss;           /* 1 float out */
+    float* state;          /* 2 words: running sum, arrival counter */
+} TfLossFuse;
+int tf_composite_forward_loss(int n_rays, const int* app_offset, const int* app_count, const float* app_w,
+                              const float* rgb, const float* acc, int white_bg, float* rgb_map, float* rgb_pre,
+                              const int* counters, long long* n_shaded, const TfLossFuse* fuse, tf_stream_t stream);
 
 /* compute_densityfeature / compute_appfeature on an explicit point list (normalised coordinates),
  * the public hooks used by compute_alpha (tensorBase.py:298-318): out_f (S) / out_feat (S, app_dim). */
