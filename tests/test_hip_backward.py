@@ -333,3 +333,40 @@ def test_binned_scatter_refuses_positions_outside_its_buffers(recon):
     torch.cuda.synchronize()
     with pytest.raises(recon._hip.HipError, match="refused out-of-range"):
         model.check_scatter_status()
+
+
+@pytest.mark.gpu
+def test_compositing_launch_forms_loss_and_gradient(recon):
+    """tf_composite_forward_loss (the captured step's form of train.py:334): the compositing launch also writes
+    mean((rgb_map - target)^2) and its gradient.  Gradient: the same expression as tf_mse_grad, element for element;
+    loss: the same sum in another order.  Run twice: the kernel re-arms its two state words itself."""
+    import ctypes as C
+    c = Case("vm_cubic_train")
+    dev = "cuda:0"
+    model = build_model(recon, c, dev)
+    rays = c.rays.to(dev)
+    target = torch.from_numpy(c.expect("grad/target")).to(dev)
+    H = recon._hip
+    grad = torch.zeros_like(target)
+    loss, state = torch.full((), -1.0, device=dev), torch.zeros(2, device=dev)
+    f = H.TfLossFuse()
+    f.target, f.grad_scale, f.grad, f.loss, f.state = target.data_ptr(), 0.5, grad.data_ptr(), loss.data_ptr(), state.data_ptr()
+    for rep in range(2):
+        model._loss_fuse = f
+        try:
+            torch.manual_seed(c.call["seed"])
+            rgb, _, _ = model(rays, None, white_bg=True, is_train=True, N_samples=c.call["N_samples"])
+        finally:
+            model._loss_fuse = None
+        torch.cuda.synchronize()
+        ref_loss = torch.mean((rgb.detach() - target) ** 2)
+        ref_grad = torch.empty_like(target)
+        ref_l = torch.zeros((), device=dev)
+        H.check(H.lib().tf_mse_grad(rgb.detach().data_ptr(), target.data_ptr(), target.numel(), 0.5, ref_l.data_ptr(),
+                                    ref_grad.data_ptr(), None), "tf_mse_grad")
+        torch.cuda.synchronize()
+        assert torch.equal(grad, ref_grad)
+        assert abs(loss.item() - ref_loss.item()) <= 1e-6 * abs(ref_loss.item()) + 1e-12
+        assert state.abs().max().item() == 0.0
+        grad.zero_()
+        loss.fill_(-1.0)
