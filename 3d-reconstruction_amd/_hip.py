@@ -81,7 +81,7 @@ class TfBinJob(C.Structure):
                 ("tile", C.c_int), ("bucket", C.c_int), ("chunk", C.c_int),
                 ("hist", _fp), ("offsets", _fp), ("cursor", _fp), ("chunk_off", _fp), ("binned", _fp),
                 ("nkeys", C.c_int), ("hist_zeroed", C.c_int), ("stage", C.c_int), ("binned_cap", C.c_int),
-                ("items_cap", C.c_int), ("status", _fp)]
+                ("items_cap", C.c_int), ("share_groups", C.c_int), ("status", _fp)]
 
 
 class TfLossFuse(C.Structure):
@@ -160,7 +160,7 @@ _SIGS = {
                           C.POINTER(TfFactorGrads), _fp, _fp, _fp],
     "tf_shade_backward_wslab_floats": [C.POINTER(TfShade)],
     "tf_shade_backward_supported": [C.POINTER(TfShade)],
-    "tf_bin_nkeys": [C.c_int, C.POINTER(C.c_int * 3), C.POINTER(C.c_int * 3), C.c_int, C.c_int],
+    "tf_bin_nkeys": [C.c_int, C.POINTER(C.c_int * 3), C.POINTER(C.c_int * 3), C.c_int, C.c_int, C.c_int],
     "tf_bin_keys_per_entry": [C.c_int, C.POINTER(C.c_int * 3)],
     "tf_binned_scatter": [C.POINTER(TfBinJob), _fp],
     "tf_binned_sort_pair": [C.POINTER(TfBinJob), C.POINTER(TfBinJob), _fp],

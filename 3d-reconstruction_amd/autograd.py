@@ -62,9 +62,13 @@ def _grad_buffers(named, n_rep=N_REP):
 def _bin_job(model, ws, part, factors, grid, stage, fgrads=None, grad=None, grad_ld=0):
     """TfBinJob of the density / appearance gradient scatter; every job owns its sort workspace."""
     app = part == "app"
-    nkeys = ws.binned_cfg[1 if app else 0]
+    # sorted early (stage 1, then 2), beside tf_shade_forward: one key per 16-component group — the cheaper shared-key sort
+    # slows the shading kernel it runs beside by more than it saves (DESIGN 5.1); sorted in the backward (stage 0): shared keys
+    share = 0 if stage in (1, 2) else 1
+    nkeys = ws.binned_cfg[(5 if app else 4) if share else (1 if app else 0)]
     nmax = max(ws.binned_cfg[0], ws.binned_cfg[1])
     j = H.TfBinJob()
+    j.share_groups = share
     j.model = H.MODEL_CP if model._is_cp() else H.MODEL_VM
     j.factors = factors
     if fgrads is not None:

@@ -13,6 +13,11 @@
 //                block once with contiguous global atomics (rows of (T+1) x C floats).
 // Every sample's contribution is computed exactly as in the direct scatter (tf_device.h), only the
 // accumulation order changes.
+// Wide decompositions are handled in 16-component groups (small private blocks); the groups of a plane / line share its
+// tiles / buckets, so the sort knows ONE key per (sample, plane | line) and the work-item table carries the group: a
+// (key, chunk) pair appears once per group, all of them walking the same slice of binned[].  (One key per group made the
+// sort's LDS atomics — 3 cycles per lane each, its whole cost — grow with the component count: 18 keys per appearance
+// sample at 48 components, 54 for TensorCP at 288.)
 #include "tf_device.h"
 
 using namespace tf;
@@ -26,13 +31,16 @@ struct KeyMap {
     int T, LB;
     int tsh, lsh;             // log2(T), log2(LB): tile and bucket sizes are powers of two (no integer divides per entry)
     int ntx[3], ptiles[3], lbuckets[3], ncg[3];
+    int share;                // 1: the component groups of a plane / line share its keys (the work items carry the group);
+                              // 0: one key per (tile | bucket, group), laid out group-major behind plane_base / line_base
     int plane_base[3], line_base[3];
     int nkeys, keys_per_entry;
 };
 
 // cp: TensorCP has line tensors only (all with n_comp[0] components): no plane keys
-__host__ __device__ inline KeyMap make_keymap(const int grid[3], const int n_comp[3], int T, int LB, bool cp = false) {
+__host__ __device__ inline KeyMap make_keymap(const int grid[3], const int n_comp[3], int T, int LB, bool cp, bool share) {
     KeyMap K;
+    K.share = share ? 1 : 0;
     K.T = T;
     K.LB = LB;
     K.tsh = K.lsh = 0;
@@ -45,13 +53,13 @@ __host__ __device__ inline KeyMap make_keymap(const int grid[3], const int n_com
         K.ntx[i] = (W + T - 1) / T;
         K.ptiles[i] = cp ? 0 : K.ntx[i] * ((H + T - 1) / T);
         K.plane_base[i] = run;
-        run += K.ptiles[i] * K.ncg[i];
-        kpe += (cp ? 1 : 2) * K.ncg[i];
+        run += K.ptiles[i] * (share ? 1 : K.ncg[i]);
+        kpe += (cp ? 1 : 2) * K.ncg[i];       // (key, group) pairs per entry: what the work-item table is sized by
     }
     for (int i = 0; i < 3; ++i) {
         K.lbuckets[i] = (grid[2 - i] + LB - 1) / LB;
         K.line_base[i] = run;
-        run += K.lbuckets[i] * K.ncg[i];
+        run += K.lbuckets[i] * (share ? 1 : K.ncg[i]);
     }
     K.nkeys = run;
     K.keys_per_entry = kpe;
@@ -72,7 +80,7 @@ __device__ __forceinline__ void sample_geom(const int grid[3], const float u[3],
     }
 }
 
-// keys of channel group 0: keys[i] (plane i) and keys[3+i] (line i); group g adds g*ptiles[i] / g*lbuckets[i]
+// keys[i] (plane i) and keys[3+i] (line i)
 __device__ __forceinline__ void sample_keys(const KeyMap& K, const int grid[3], const SampleGeom& g, int keys[6]) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -84,10 +92,17 @@ __device__ __forceinline__ void sample_keys(const KeyMap& K, const int grid[3], 
 }
 #define TF_FOR_EACH_KEY(K, keys, key, BODY)                                   \
     _Pragma("unroll") for (int _i = 0; _i < 3; ++_i)                          \
-        for (int _g = 0; _g < (K).ncg[_i]; ++_g) {                            \
+        for (int _g = 0; _g < ((K).share ? 1 : (K).ncg[_i]); ++_g) {          \
             if ((K).ptiles[_i]) { const int key = (keys)[_i] + _g * (K).ptiles[_i]; BODY; } \
             { const int key = (keys)[3 + _i] + _g * (K).lbuckets[_i]; BODY; } \
         }
+// component groups a key's work items fan out to (shared keys: those of the plane / line it belongs to)
+__device__ __forceinline__ int key_groups(const KeyMap& K, int key) {
+    if (!K.share) return 1;
+    if (key >= K.line_base[0]) return K.ncg[key >= K.line_base[2] ? 2 : (key >= K.line_base[1] ? 1 : 0)];
+    return K.ncg[key >= K.plane_base[2] ? 2 : (key >= K.plane_base[1] ? 1 : 0)];
+}
+constexpr int kItemKeyBits = 20;       // work item = key | group << 20  (TF_BIN_MAX_KEYS = 2^18 keys, <= 2^11 groups)
 
 // threads per workgroup and workgroups per entry shard of the count / fill passes (measured at config 2:
 // 1 / 2 / 4 / 8 / 16 slices -> count 23 / 15 / 12.5 / 15 / 22 us, fill 50 / 32 / 24 / 31 / 50 us; 1024 threads: no change)
@@ -113,6 +128,8 @@ __device__ __forceinline__ void flag(const TfBinJob& J, int bit) {
     if (J.status) atomicOr(J.status, bit);
 }
 
+constexpr int kScanThreads = 1024;  // the scan runs beside tf_shade_forward on some CU: a small workgroup (4 waves) slows the
+                                   // shading workgroup it shares that CU with far less than 16 waves did
 constexpr int kKeyRange = 16384;   // keys per LDS pass of the count / scan / fill kernels (64 KB of ints)
 
 // entries of shard g handled by slice k: local = k*256 + tid, += kSlices*256.  Jobs with more than kKeyRange keys
@@ -151,31 +168,40 @@ __global__ __launch_bounds__(kSortThreads) void bin_count_kernel(const SortArgs 
 // kernel a chain of memory latencies).  The kernel is kept SMALL on purpose (no per-thread register copy of the
 // histogram slice: 1024 threads at 128 VGPRs need a whole empty CU, and the training step runs this kernel next to
 // tf_shade_forward on a second stream).
-__global__ __launch_bounds__(1024, 8) void bin_scan_kernel(const SortArgs A) {
-    extern __shared__ int sh[];                 // hist copy of the current key range, then its prefixes
-    const TfBinJob& J = A.J[blockIdx.x];
-    const int nkeys = A.K[blockIdx.x].nkeys, csh = A.csh[blockIdx.x];
-    __shared__ int part[17], part2[17];
+// (one workgroup per job; the job is a template parameter — indexing the by-value argument arrays with blockIdx.x made the
+// compiler build pointer / key-map tables in scratch memory)
+template <int JOB>
+__device__ __forceinline__ void scan_job(const SortArgs& A, int* sh) {
+    const TfBinJob& J = A.J[JOB];
+    const KeyMap& KM = A.K[JOB];
+    const int nkeys = KM.nkeys, csh = A.csh[JOB];
+    const int lb0 = KM.line_base[0], lb1 = KM.line_base[1], lb2 = KM.line_base[2];
+    const int pb1 = KM.plane_base[1], pb2 = KM.plane_base[2];
+    const int g0 = KM.share ? KM.ncg[0] : 1, g1 = KM.share ? KM.ncg[1] : 1, g2 = KM.share ? KM.ncg[2] : 1;
+#define groups_of(key) ((key) >= lb0 ? ((key) >= lb2 ? g2 : ((key) >= lb1 ? g1 : g0)) : ((key) >= pb2 ? g2 : ((key) >= pb1 ? g1 : g0)))
+    constexpr int NT = kScanThreads, NWV = NT / 64;
+    __shared__ int part[NWV + 1], part2[NWV + 1];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // item table: work item -> key (chunk index = item - chunk_off[key]); lives behind chunk_off[]
+    // item table: work item -> key | group << kItemKeyBits; a key's items are laid out group by group, so the chunk index
+    // is (item - chunk_off[key]) - group * chunks(key); lives behind chunk_off[]
     int* items = J.chunk_off + nkeys + 1;
     const int cm1 = J.chunk - 1;
     int carry = 0, carry2 = 0;
     for (int k0 = 0; k0 < nkeys; k0 += kKeyRange) {
         const int kn = min(kKeyRange, nkeys - k0);
         __syncthreads();                        // the previous range's copy-out has finished reading sh / part
-        for (int i = tid; i < kn; i += 1024) sh[i] = J.hist[k0 + i];
+        for (int i = tid; i < kn; i += NT) sh[i] = J.hist[k0 + i];
         __syncthreads();
-        constexpr int kPer = kKeyRange / 1024;  // keys per thread (contiguous)
-        const int lo = tid * kPer, hi = min(kn, (tid + 1) * kPer);
+        const int kPer = (kn + NT - 1) / NT;    // keys per thread (contiguous)
+        const int lo = min(kn, tid * kPer), hi = min(kn, (tid + 1) * kPer);
         int s = 0, s2 = 0;
 #pragma unroll 1
         for (int i = lo; i < hi; ++i) {
             const int h = sh[i];
             s += h;
-            s2 += (h + cm1) >> csh;
+            s2 += ((h + cm1) >> csh) * groups_of(k0 + i);
         }
-        // inclusive scan over the 1024 threads: shuffles inside each wave, then the 16 wave totals
+        // inclusive scan over the threads: shuffles inside each wave, then the wave totals
         int v = s, v2 = s2;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -190,28 +216,28 @@ __global__ __launch_bounds__(1024, 8) void bin_scan_kernel(const SortArgs A) {
             part2[wv] = v2;
         }
         __syncthreads();
-        if (wv == 0) {      // exclusive scan of the 16 wave totals; slot 16 = grand total
-            int a = lane < 16 ? part[lane] : 0, b = lane < 16 ? part2[lane] : 0;
+        if (wv == 0) {      // exclusive scan of the wave totals; slot NWV = grand total
+            int a = lane < NWV ? part[lane] : 0, b = lane < NWV ? part2[lane] : 0;
             const int a0 = a, b0 = b;
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
+            for (int o = 1; o < NWV; o <<= 1) {
                 const int x = __shfl_up(a, o, 64), y = __shfl_up(b, o, 64);
                 if (lane >= o) {
                     a += x;
                     b += y;
                 }
             }
-            if (lane < 16) {
+            if (lane < NWV) {
                 part[lane] = a - a0;
                 part2[lane] = b - b0;
             }
-            if (lane == 15) {
-                part[16] = a;
-                part2[16] = b;
+            if (lane == NWV - 1) {
+                part[NWV] = a;
+                part2[NWV] = b;
             }
         }
         __syncthreads();
-        const int wbase = part[wv], wbase2 = part2[wv], tot = part[16], tot2 = part2[16];
+        const int wbase = part[wv], wbase2 = part2[wv], tot = part[NWV], tot2 = part2[NWV];
         // The per-thread key ranges are contiguous, so writing the prefixes straight to global memory would be one
         // cache line per lane and store; they go to LDS (in place of the histogram) and leave with coalesced stores.
         int run = carry + v + wbase - s, run2 = carry2 + v2 + wbase2 - s2;
@@ -219,16 +245,12 @@ __global__ __launch_bounds__(1024, 8) void bin_scan_kernel(const SortArgs A) {
         for (int i = lo; i < hi; ++i) {
             const int h = sh[i];
             sh[i] = run;
-            const int nc = (h + cm1) >> csh;
-            for (int c = 0; c < nc; ++c) {
-                if (run2 + c < J.items_cap) items[run2 + c] = k0 + i;
-                else flag(J, TF_BIN_ERR_ITEMS);
-            }
+            const int nc = (h + cm1) >> csh, ng = nc ? groups_of(k0 + i) : 0;
             run += h;
-            run2 += nc;
+            run2 += nc * ng;
         }
         __syncthreads();
-        for (int i = tid; i < kn; i += 1024) {
+        for (int i = tid; i < kn; i += NT) {
             const int o = sh[i];
             J.offsets[k0 + i] = o;
             J.cursor[k0 + i] = o;
@@ -242,18 +264,40 @@ __global__ __launch_bounds__(1024, 8) void bin_scan_kernel(const SortArgs A) {
         for (int i = lo; i < hi; ++i) {
             const int next = i + 1 < hi ? sh[i + 1] : run;
             sh[i] = run2;
-            run2 += (next - prev + cm1) >> csh;
+            run2 += ((next - prev + cm1) >> csh) * groups_of(k0 + i);
             prev = next;
         }
         __syncthreads();
-        for (int i = tid; i < kn; i += 1024) J.chunk_off[k0 + i] = sh[i];
+        for (int i = tid; i < kn; i += NT) {
+            const int co = sh[i];
+            J.chunk_off[k0 + i] = co;
+            // the key's work items, group by group.  Keys are dealt round robin: occupied tiles come in runs, and a thread
+            // that owned a whole run wrote all of its items alone (the kernel's critical path).  The key's item count is
+            // the difference of neighbouring prefixes (LDS): no global load in this loop — the kernel runs beside
+            // tf_shade_forward, where a dependent load costs microseconds
+            const int n_it = (i + 1 < kn ? sh[i + 1] : carry2 + tot2) - co;
+            const int ng = n_it ? groups_of(k0 + i) : 0, nc = ng > 1 ? n_it / ng : n_it;
+            for (int g = 0; g < ng; ++g)
+                for (int c = 0; c < nc; ++c) {
+                    if (co + g * nc + c < J.items_cap) items[co + g * nc + c] = (k0 + i) | (g << kItemKeyBits);
+                    else flag(J, TF_BIN_ERR_ITEMS);
+                }
+        }
         carry += tot;
         carry2 += tot2;
     }
-    if (tid == 1023) {
+    if (tid == NT - 1) {
         J.offsets[nkeys] = carry;
         J.chunk_off[nkeys] = carry2;
     }
+}
+
+#undef groups_of
+
+__global__ __launch_bounds__(kScanThreads) void bin_scan_kernel(const SortArgs A) {
+    extern __shared__ int sh[];                 // hist copy of the current key range, then its prefixes
+    if (blockIdx.x == 0) scan_job<0>(A, sh);
+    else scan_job<1>(A, sh);
 }
 
 __global__ __launch_bounds__(kSortThreads) void bin_fill_kernel(const SortArgs A) {
@@ -343,28 +387,42 @@ __global__ __launch_bounds__(256, 4) void bin_scatter_kernel(const TfBinJob J, c
         float* pre = smem + wave * wstride;            // [ER][C]
         float* meta = pre + ER * cmax;                 // [ER][8]: cell (int), w00, w01, w10, w11 | cell, w0, w1
         float* blk0 = smem + 4 * wstride;              // 4 private accumulation blocks (one per wave)
-        const int key = J.chunk_off[K.nkeys + 1 + w];
-        if ((unsigned)key >= (unsigned)K.nkeys) {       // not a key: an item slot the scan never wrote
+        const int item = J.chunk_off[K.nkeys + 1 + w];
+        const int key = item & ((1 << kItemKeyBits) - 1);
+        int cg = (int)((unsigned)item >> kItemKeyBits);
+        if ((unsigned)key >= (unsigned)K.nkeys || cg >= key_groups(K, key)) {   // not an item: a slot the scan never wrote
             if (threadIdx.x == 0) flag(J, TF_BIN_ERR_ITEMS);
             continue;
         }
-        const int chunk = w - J.chunk_off[key];
-        int beg = J.offsets[key] + chunk * J.chunk, end = min(J.offsets[key + 1], beg + J.chunk);
+        const int kbeg = J.offsets[key], kend = J.offsets[key + 1];
+        const int nchunks = (kend - kbeg + J.chunk - 1) / J.chunk;
+        const int chunk = (w - J.chunk_off[key]) - cg * nchunks;          // the key's items: group by group
+        if (chunk < 0 || chunk >= nchunks) {
+            if (threadIdx.x == 0) flag(J, TF_BIN_ERR_ITEMS);
+            continue;
+        }
+        int beg = kbeg + chunk * J.chunk, end = min(kend, beg + J.chunk);
         if (beg < 0 || end > J.binned_cap) {      // (ranges outside binned[] are dropped and reported)
             if (threadIdx.x == 0) flag(J, TF_BIN_ERR_BINNED);
             beg = max(beg, 0);
             end = min(end, J.binned_cap);
         }
         const bool is_line = key >= K.line_base[0];
-        int i = 0, local = 0, cg = 0;
+        int i = 0, local = 0;
         if (is_line) {
             i = key >= K.line_base[2] ? 2 : (key >= K.line_base[1] ? 1 : 0);
-            cg = (key - K.line_base[i]) / K.lbuckets[i];
-            local = (key - K.line_base[i]) - cg * K.lbuckets[i];
+            local = key - K.line_base[i];
+            if (!K.share) {
+                cg = local / K.lbuckets[i];
+                local -= cg * K.lbuckets[i];
+            }
         } else {
             i = key >= K.plane_base[2] ? 2 : (key >= K.plane_base[1] ? 1 : 0);
-            cg = (key - K.plane_base[i]) / K.ptiles[i];
-            local = (key - K.plane_base[i]) - cg * K.ptiles[i];
+            local = key - K.plane_base[i];
+            if (!K.share) {
+                cg = local / K.ptiles[i];
+                local -= cg * K.ptiles[i];
+            }
         }
         const bool cp = J.model == TF_MODEL_CP;
         const int CF = J.factors.n_comp[cp ? 0 : i];  // components of the factor tensor (memory stride)
@@ -554,16 +612,16 @@ int tf_bin_status(const int* status, int* bits_out, tf_stream_t stream) {
     return bits ? (int)hipErrorAssert : 0;
 }
 
-int tf_bin_nkeys(int model, const int grid[3], const int n_comp[3], int tile, int bucket) {
-    return make_keymap(grid, n_comp, tile, bucket, model == TF_MODEL_CP).nkeys;
+int tf_bin_nkeys(int model, const int grid[3], const int n_comp[3], int tile, int bucket, int share) {
+    return make_keymap(grid, n_comp, tile, bucket, model == TF_MODEL_CP, share != 0).nkeys;
 }
 int tf_bin_keys_per_entry(int model, const int n_comp[3]) {
     const int grid1[3] = {8, 8, 8};
-    return make_keymap(grid1, n_comp, 8, 8, model == TF_MODEL_CP).keys_per_entry;
+    return make_keymap(grid1, n_comp, 8, 8, model == TF_MODEL_CP, true).keys_per_entry;
 }
 
 static bool job_shape_ok(const TfBinJob* job, KeyMap& K) {
-    K = make_keymap(job->grid, job->factors.n_comp, job->tile, job->bucket, job->model == TF_MODEL_CP);
+    K = make_keymap(job->grid, job->factors.n_comp, job->tile, job->bucket, job->model == TF_MODEL_CP, job->share_groups != 0);
     if (K.nkeys != job->nkeys || K.nkeys > TF_BIN_MAX_KEYS) return false;
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
     return pow2(job->tile) && pow2(job->bucket) && pow2(job->chunk);
@@ -588,13 +646,17 @@ static int launch_sort(const TfBinJob* const jobs[2], int n, hipStream_t st) {
         A.K[1] = A.K[0];
         A.csh[1] = A.csh[0];
     }
-    const size_t lds = sizeof(int) * (size_t)kr;
+    // At least 48 KB of LDS per workgroup although the shared keys need far less: in the training step these kernels run
+    // beside tf_shade_forward, whose workgroups leave ~78 KB free on the CUs that hold one of them — with 18 KB histograms
+    // four sort workgroups (16 waves of LDS atomics) moved in next to that one shading workgroup, and the evenly dealt
+    // shading kernel waited for those CUs: 200 us instead of 150.
+    const size_t lds_need = sizeof(int) * (size_t)kr, lds = lds_need < 53352 ? 53352 : lds_need;
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(bin_count_kernel), (size_t)(lds));
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(bin_count_kernel, dim3(n * kSortWgs), dim3(kSortThreads), lds, st, A);
     e = ensure_dynamic_lds(reinterpret_cast<const void*>(bin_scan_kernel), (size_t)(lds));
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(n), dim3(1024), lds, st, A);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(n), dim3(kScanThreads), lds, st, A);
     e = ensure_dynamic_lds(reinterpret_cast<const void*>(bin_fill_kernel), (size_t)(lds));
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(bin_fill_kernel, dim3(n * kSortWgs), dim3(kSortThreads), lds, st, A);

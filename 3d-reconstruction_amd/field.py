@@ -661,11 +661,15 @@ class TensorBase(nn.Module):
                 # than the sort's LDS tables hold (~400^3 at 48 components); beyond that the direct scatter
                 # (per-tap atomics, line replicas) takes over
                 for tile in (self.bin_tile, 2 * self.bin_tile):
-                    binned = (int(lib.tf_bin_nkeys(mdl, C.byref(g3), C.byref(cd), tile, self.bin_bucket)),
-                              int(lib.tf_bin_nkeys(mdl, C.byref(g3), C.byref(ca), tile, self.bin_bucket)),
+                    # [0], [1]: keys with one key per 16-component group (sizes the workspace; the captured step sorts this
+                    # way), [4], [5]: keys shared by the groups of a plane / line (every other step)
+                    binned = (int(lib.tf_bin_nkeys(mdl, C.byref(g3), C.byref(cd), tile, self.bin_bucket, 0)),
+                              int(lib.tf_bin_nkeys(mdl, C.byref(g3), C.byref(ca), tile, self.bin_bucket, 0)),
                               max(int(lib.tf_bin_keys_per_entry(mdl, C.byref(cd))),
                                   int(lib.tf_bin_keys_per_entry(mdl, C.byref(ca)))),
-                              tile)
+                              tile,
+                              int(lib.tf_bin_nkeys(mdl, C.byref(g3), C.byref(cd), tile, self.bin_bucket, 1)),
+                              int(lib.tf_bin_nkeys(mdl, C.byref(g3), C.byref(ca), tile, self.bin_bucket, 1)))
                     if max(binned[0], binned[1]) <= H.BIN_MAX_KEYS:
                         break
                     binned = None

@@ -341,7 +341,8 @@ typedef struct TfBinJob {
     int grad_ld;              /* 0: one scalar per entry, broadcast over components; else row stride */
     int tile, bucket, chunk;  /* T, LB, max entries per workgroup */
     /* workspace (ints): hist[nkeys] (read, then left as is), offsets[nkeys+1], cursor[nkeys], chunk_off[nkeys+1] followed by the
-     * work-item table (nkeys + kpe*entries/chunk ints); binned[kpe*entries], kpe = tf_bin_keys_per_entry */
+     * work-item table (groups*nkeys + kpe*entries/chunk ints, groups = most 16-component groups of a plane / line);
+     * binned[kpe*entries], kpe = tf_bin_keys_per_entry */
     int* hist; int* offsets; int* cursor; int* chunk_off; int* binned;
     int nkeys;
     int hist_zeroed;          /* 1: the caller has zeroed hist[0..nkeys) on this stream (saves a launch) */
@@ -350,6 +351,9 @@ typedef struct TfBinJob {
                                * only, the workspace holds the result of an earlier stage-1 call of the same job */
     int binned_cap;           /* ints in binned[]; */
     int items_cap;            /* ints in the work-item table behind chunk_off[nkeys + 1] */
+    int share_groups;         /* 1: one sort key per (sample, plane | line) — the 16-component groups share it and the work-item
+                               * table carries the group (cheapest sort: eager steps, large configurations); 0: one key per
+                               * group (what runs best beside tf_shade_forward on the second stream: the captured step) */
     int* status;              /* device word (sticky, may be NULL): the kernels OR a TF_BIN_ERR_* bit into it instead of
                                * writing / reading outside binned[], the item table or the entry list — a histogram that
                                * does not describe the entries (e.g. not zeroed) then costs a wrong gradient and this
@@ -362,9 +366,10 @@ typedef struct TfBinJob {
 int tf_bin_status(const int* status, int* bits_out, tf_stream_t stream);
 #define TF_BIN_MAX_KEYS 262144  /* tf_binned_scatter returns hipErrorInvalidValue above this (the sort walks the keys in
                                  * LDS-sized ranges of 16384; ~1000^3 grids at 48 components stay below) */
-/* Decompositions wider than 16 components are split into 16-component groups, each with its own key, so the
- * per-workgroup LDS blocks stay small.  Number of keys for (grid, n_comp, T, LB), and keys emitted per entry: */
-int tf_bin_nkeys(int model, const int grid[3], const int n_comp[3], int tile, int bucket);
+/* Decompositions wider than 16 components are handled in 16-component groups (small per-workgroup LDS blocks); the groups
+ * of a plane / line share its keys, the work-item table carries the group.  Number of keys for (grid, n_comp, T, LB), and
+ * the number of (key, group) pairs per entry — what binned[] (an upper bound) and the work-item table are sized by: */
+int tf_bin_nkeys(int model, const int grid[3], const int n_comp[3], int tile, int bucket, int share_groups);
 int tf_bin_keys_per_entry(int model, const int n_comp[3]);
 int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream);
 /* The sort stage (stage 1) of two jobs at once — three launches instead of six; b may be NULL. */
