@@ -101,10 +101,13 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
         __syncthreads();
         total = pre[TF_N_SHARDS];
     }
-    // whole 64-sample chunks, dealt evenly: workgroup b owns chunks [b C / W, (b + 1) C / W) of the C = ceil(total / 64)
-    const long long n_chunks = (total + M - 1) / M;
-    const int v_begin = (int)(((long long)blockIdx.x * n_chunks) / (long long)gridDim.x) * M;
-    const int v_end = min(total, (int)((((long long)blockIdx.x + 1) * n_chunks) / (long long)gridDim.x) * M);
+    // The list is dealt evenly in units of 16 samples (one MFMA sample tile): workgroup b owns tiles [b T / W, (b + 1) T / W)
+    // of the T = ceil(total / 16) and walks them in chunks of <= 64; its last chunk is usually a partial one, and a partial
+    // chunk costs its active sample tiles only (`nt` below).  (Dealt in whole 64-sample chunks, 1268 chunks on 512
+    // workgroups made three rounds of which the third was half empty: 2.48 chunk times of work took 3.)
+    const long long n_tiles = (total + 15) / 16;
+    const int v_begin = (int)(((long long)blockIdx.x * n_tiles) / (long long)gridDim.x) * 16;
+    const int v_end = min(total, (int)((((long long)blockIdx.x + 1) * n_tiles) / (long long)gridDim.x) * 16);
 
     // per-sample info of thread tid < 64, fetched for the NEXT chunk while the current one is processed
     // (app_ray -> rays is a chain of two global latencies)
@@ -134,6 +137,7 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
         if (!fwd_locate(src, pre, v, v_end, ck)) break;
         const int n = ck.n();
         v += n;
+        const int nt = (n + 15) >> 4, n16 = 16 * nt;      // active sample tiles / rows of this chunk
         // thread coordinates from an opaque copy of the thread id, so that no per-thread address of a later phase is
         // computed (and kept in registers) outside the chunk loop: the kernel has 128 VGPRs at 4 waves per SIMD
         int tid = threadIdx.x;
@@ -167,10 +171,12 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
         // ---- 1. appearance gather -> V: 8 lanes per sample
         if (!src.feat_in) {
             const int smp = (tid >> 6) * 8 + (lane >> 3), sub = lane & 7;
-            float u[3] = {ixyz[smp * 3], ixyz[smp * 3 + 1], ixyz[smp * 3 + 2]};
-            float* vrow = regA + smp * L.sv;
-            if (!app_products_lanes8(S, u, sub, vrow)) app_products(S, u, sub, vrow, 8);
-            for (int c = S.n_app_total + sub; c < kpad16(S.n_app_total); c += 8) vrow[c] = 0.f;
+            if (smp < n16) {
+                float u[3] = {ixyz[smp * 3], ixyz[smp * 3 + 1], ixyz[smp * 3 + 2]};
+                float* vrow = regA + smp * L.sv;
+                if (!app_products_lanes8(S, u, sub, vrow)) app_products(S, u, sub, vrow, 8);
+                for (int c = S.n_app_total + sub; c < kpad16(S.n_app_total); c += 8) vrow[c] = 0.f;
+            }
         }
         __syncthreads();
         TF_MARK(1);
@@ -193,6 +199,7 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
         }
         for (int pr = src.feat_in ? 4 * NB : wave; pr < 4 * NB; pr += NW) {
             const int bf = pr >> 2, bs = pr & 3;
+            if (bs >= nt) continue;
             f32x4 acc[1][1];
             acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
             mma_block<1, 1>(S.basis, kpad16(S.n_app_total), 16 * bf, regA, L.sv, 16 * bs, kpad16(S.n_app_total) / 16, acc, lane);
@@ -249,11 +256,11 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
                 const int sx = L.sx;
                 pe_block<NT>(regB, L.sx, off, D, F, mk, tid, [&](int smp, int d) {
                     return src_k == TF_SRC_FEAT ? xb[smp * sx + d] : (src_k == TF_SRC_VIEW ? iview[smp * 3 + d] : ixyz[smp * 3 + d]);
-                });
+                }, n16);
                 off += 2 * D * F;
             }
             const int kp = kpad16(S.in_c);
-            for (int it = tid; it < M * 16; it += NT) {       // the K padding is < 16 columns
+            for (int it = tid; it < n16 * 16; it += NT) {     // the K padding is < 16 columns
                 const int smp = it >> 4, c = S.in_c + (it & 15);
                 if (c < kp) regB[smp * L.sx + c] = 0.f;
             }
@@ -261,6 +268,7 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
         const int FC = S.feature_c, kp1 = kpad16(S.in_c), kt1 = kp1 / 16;
         const int f_base = 16 * NFW * (wave % FG), s_base = 16 * NSW * (wave / FG);
         const int lc = lane & 15, lg = lane >> 4;
+        const int nst = min(NSW, max(0, nt - NSW * (wave / FG)));      // this wave's active sample tiles
         f32x4 fr1[PRE ? KG1 : 1][1];          // layer-1 weight fragments, in flight across the barrier
         if constexpr (PRE) load_a_frags<1, KG1>(S.w1, kp1, f_base, kt1, lane, fr1);
         __syncthreads();
@@ -276,7 +284,9 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
 #pragma unroll
                 for (int j = 0; j < NSW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if constexpr (PRE) {
-                mma_frags<1, NSW, KG1>(fr1, regB, L.sx, s_base, kt1, acc, lane);
+                // (a partial chunk: the wave multiplies the first half of its sample tiles only)
+                if (NSW == 1 || 2 * nst > NSW) mma_frags<1, NSW, KG1>(fr1, regB, L.sx, s_base, kt1, acc, lane);
+                else if (nst > 0) mma_frags<1, (NSW > 1 ? NSW / 2 : 1), KG1>(fr1, regB, L.sx, s_base, kt1, reinterpret_cast<f32x4 (&)[1][NSW > 1 ? NSW / 2 : 1]>(acc), lane);
                 load_a_frags<1, FT>(S.w2, kpad16(FC), f_base, FT, lane, fr2);     // layer 2's weights: behind this epilogue
             } else {
                 mma_block<NFW, NSW>(S.w1, kp1, f_base, regB, L.sx, s_base, kt1, acc, lane);
@@ -287,6 +297,7 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
                 const f32x4 bias = *reinterpret_cast<const f32x4*>(S.b1 + f);
 #pragma unroll
                 for (int j = 0; j < NSW; ++j) {
+                    if (PRE && j >= nst) continue;
                     f32x4 h = acc[i][j] + bias;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) h[e] = fmaxf(h[e], 0.f);
@@ -307,7 +318,10 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
             for (int i = 0; i < NFW; ++i)
 #pragma unroll
                 for (int j = 0; j < NSW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if constexpr (PRE) mma_frags<1, NSW, FT>(fr2, regA, L.sh, s_base, FT, acc, lane);
+            if constexpr (PRE) {
+                if (NSW == 1 || 2 * nst > NSW) mma_frags<1, NSW, FT>(fr2, regA, L.sh, s_base, FT, acc, lane);
+                else if (nst > 0) mma_frags<1, (NSW > 1 ? NSW / 2 : 1), FT>(fr2, regA, L.sh, s_base, FT, reinterpret_cast<f32x4 (&)[1][NSW > 1 ? NSW / 2 : 1]>(acc), lane);
+            }
             else mma_block<NFW, NSW>(S.w2, kpad16(FC), f_base, regA, L.sh, s_base, FC / 16, acc, lane);
 #pragma unroll
             for (int i = 0; i < NFW; ++i) {
@@ -315,6 +329,7 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
                 const f32x4 bias = *reinterpret_cast<const f32x4*>(S.b2 + f);
 #pragma unroll
                 for (int j = 0; j < NSW; ++j) {
+                    if (PRE && j >= nst) continue;
                     f32x4 h = acc[i][j] + bias;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) h[e] = fmaxf(h[e], 0.f);
@@ -325,7 +340,7 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
         __syncthreads();
         TF_MARK(5);
         if (save.h2) save_rows<NT>(save.h2, regB, L.sh, FC, n, tid, at);
-        if (wave < 4) {      // all at once (unconditional loads, rows >= 3 zeroed after)
+        if (wave < nt) {     // all at once (unconditional loads, rows >= 3 zeroed after)
             const int r3 = lc < 3 ? lc : 2;
 #pragma unroll
             for (int k = 0; k < KG3; ++k) {
@@ -338,7 +353,7 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
         // ---- 5. output layer + sigmoid on the MFMA: o[c][s] = sum_f W3[c][f] H2[s][f], W3 as rows 0..2 of a 16-row
         // operand tile; wave w < 4 takes sample tile w (the other waves go on to the next chunk's info phase — nothing
         // they write there is read here)
-        if (wave < 4) {
+        if (wave < nt) {
             const int r = lane & 15, kq = lane >> 4;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};      // two chains: no dependent-MFMA stalls
             const float* xp = regB + (16 * wave + r) * L.sh + 4 * kq;

@@ -261,10 +261,11 @@ __device__ __forceinline__ bool app_products_lanes8(const TfShade& S, const floa
 // `val(smp, d)` supplies v.  NT threads cooperate.  The F evaluations of an item are independent and evaluated
 // branch-free two at a time unless some lane of the wave holds a huge argument (wave-uniform test).
 template <int NT, typename ValFn>
-__device__ __forceinline__ void pe_block(float* X, int sx, int off, int D, int F, const float* mk, int tid, ValFn val) {
+__device__ __forceinline__ void pe_block(float* X, int sx, int off, int D, int F, const float* mk, int tid, ValFn val,
+                                         int rows = M) {
     // thread -> (sample, dim) without integer division: dims padded to a power of two
     const int dp = D <= 4 ? 4 : (D <= 32 ? 32 : 64), dsh = D <= 4 ? 2 : (D <= 32 ? 5 : 6);
-    for (int it = tid; it < M * dp; it += NT) {
+    for (int it = tid; it < rows * dp; it += NT) {
         const int smp = it >> dsh, d = it & (dp - 1);
         const bool on = d < D;
         float* x = X + smp * sx;
