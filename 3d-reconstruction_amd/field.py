@@ -270,8 +270,9 @@ class TensorBase(nn.Module):
         self.early_sort = False
         self._sort_stream = None
         # tf_shade_forward workgroups (of 512 CU slots) while the early sorts run next to it; the sort kernels need a CU
-        # slot's LDS and registers (measured at config 2, 432 ... 512 in steps of 16: 0.882 - 0.889 ms per step, flat within the run-to-run noise)
-        self.shade_wgs_beside_sort = 448
+        # slot's LDS and registers (measured at config 2 with the 16-sample work split: 384 / 448 / 480 / 496 / 504 / 512 workgroups ->
+        # 0.759 / 0.737 / 0.734 / 0.732 / 0.731 / 0.736 ms per step)
+        self.shade_wgs_beside_sort = 496
         self.bin_tile, self.bin_bucket, self.bin_chunk = 8, 8, 512
         self._jitter_override = None   # tests: inject the stratified jitter instead of drawing it
         self._bg_override = None       # GraphedTrainStep: outcome of the random-background draw of tensorBase.py:380
