@@ -77,7 +77,7 @@ def _bin_job(model, ws, part, factors, grid, stage, fgrads=None, grad=None, grad
     j.counters, j.slot, j.seg_cap = ws.counters.data_ptr(), (0 if app else 3), ws.seg_cap
     j.xyz = (ws.app_xyz if app else ws.ent_xyz).data_ptr()
     j.grad, j.grad_ld = (grad.data_ptr() if grad is not None else None), grad_ld
-    j.tile, j.bucket, j.chunk = ws.binned_cfg[3], model.bin_bucket, model.bin_chunk
+    j.tile, j.bucket, j.chunk = ws.binned_cfg[3], model.bin_bucket, (model.bin_chunk if share else model.bin_chunk_early)
     ints = (ws.bin_ints_app if app else ws.bin_ints).data_ptr()
     j.hist = (ws.hist_app if app else ws.hist_density).data_ptr()
     j.hist_zeroed = 1                     # zeroed with the shard counters at the start of the forward

@@ -199,7 +199,7 @@ class _Workspace:
                      ("xs", cap * kp_in, torch.float32), ("h1s", cap * fc, torch.float32), ("h2s", cap * fc, torch.float32)]
             if binned is not None:   # binned gradient scatter (csrc/bin.hip): entry lists + sort workspace
                 nkeys, kpe = max(binned[0], binned[1]), binned[2]
-                n_ints = 4 * (nkeys + 8) + kpe * cap // 256 + 64
+                n_ints = 4 * (nkeys + 8) + kpe * cap // 128 + 64      # work items: <= pairs / chunk + keys, chunk >= 256
                 # one sort workspace per job (density, appearance): both sorts run early, next to the shading kernels
                 spec += [("bin_status", 64, torch.int32),
                          ("ent_xyz", cap * 3, torch.float32), ("ent_df", cap, torch.float32), ("ent_offset", R, torch.int32),
@@ -274,6 +274,10 @@ class TensorBase(nn.Module):
         # 0.759 / 0.737 / 0.734 / 0.732 / 0.731 / 0.736 ms per step)
         self.shade_wgs_beside_sort = 496
         self.bin_tile, self.bin_bucket, self.bin_chunk = 8, 8, 512
+        # entries per work item when the sorts run early — steps with few samples (EARLY_SORT_LIMITS), where 512-entry items
+        # leave the scatter kernels short of workgroups: 0.731 -> 0.722 ms per captured step at config 2 (the large
+        # configurations and eager steps are better off with 512)
+        self.bin_chunk_early = 256
         self._jitter_override = None   # tests: inject the stratified jitter instead of drawing it
         self._bg_override = None       # GraphedTrainStep: outcome of the random-background draw of tensorBase.py:380
         self._loss_fuse = None         # GraphedTrainStep: TfLossFuse — the compositing launch also forms the loss and its gradient
