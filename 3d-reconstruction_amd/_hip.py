@@ -121,7 +121,7 @@ class TfAdamSeg(C.Structure):
 
 
 class TfAdamJob(C.Structure):
-    _fields_ = [("n_seg", C.c_int), ("pad_", C.c_int), ("seg", TfAdamSeg * ADAM_MAX_SEG),
+    _fields_ = [("n_seg", C.c_int), ("clear_grads", C.c_int), ("seg", TfAdamSeg * ADAM_MAX_SEG),
                 ("chunk_end", C.c_int * ADAM_MAX_SEG), ("lrs", _fp), ("step", _fp),
                 ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("step_rw", _fp), ("arrivals", _fp), ("touched", _fp)]
 

@@ -48,13 +48,25 @@ def _grad_layout(named):
     return _LAYOUTS[key]
 
 
-def _grad_buffers(named, n_rep=N_REP):
+def _grad_buffers(named, n_rep=N_REP, store=None):
     """One zero-filled allocation: [line gradients | all other gradients | n_rep replicas of the line block].
     The direct-scatter kernels spread line-gradient atomics over the replicas; tf_reduce_replicas folds them
     into the head of the buffer, so flat[:grad_len] is every parameter gradient of the step, contiguous (one
-    all-reduce).  The binned scatter flushes each line bucket once per work item and needs no replicas."""
+    all-reduce).  The binned scatter flushes each line bucket once per work item and needs no replicas.
+    `store` (graph.GraphedTrainStep, binned scatter only): {'flat', 'clean'} — a buffer that lives across steps; its
+    owner's optimizer returns the gradients it consumed to zero (FusedAdam.consume_grads), so a clean buffer is handed out
+    as it is: no 70 MB fill per step at config 2."""
     offs, total, line_len, layout = _grad_layout(named)
-    flat = torch.zeros(total + n_rep * line_len, dtype=torch.float32, device=named[0][1].device)
+    dev = named[0][1].device
+    if store is not None and n_rep == 0:
+        flat = store.get('flat')
+        if flat is None or flat.numel() != total or flat.device != dev:
+            flat = store['flat'] = torch.zeros(total, dtype=torch.float32, device=dev)
+        elif not store.get('clean', False):      # (a step that never reached its optimizer: an exception, a dropped loss)
+            flat.zero_()
+        store['clean'] = False
+    else:
+        flat = torch.zeros(total + n_rep * line_len, dtype=torch.float32, device=dev)
     views = {name: torch.as_strided(flat, size, stride, off) for name, size, stride, off in layout}
     return views, flat, offs, total, line_len
 
@@ -109,7 +121,7 @@ def _early_sort(model, ws, field, shade, named):
                      C.byref(_bin_job(model, ws, "density", field.density, field.grid, 1)),
                      C.byref(_bin_job(model, ws, "app", shade.app, field.grid, 1)), st)
         # the step's (zero-filled) gradient buffer is produced here as well: 70 MB of fill off the main stream
-        bufs = _grad_buffers(named, 0)
+        bufs = _grad_buffers(named, 0, getattr(model, "_grad_store", None))
         bufs[1].record_stream(main)
     return side, bufs
 
@@ -170,7 +182,7 @@ def backward_launches(model, c, named, g_rgb, early_bufs=None, stage="all"):
         if presorted and early_bufs is not None:   # made on the second stream during the forward (_early_sort)
             grads, flat, offs, grad_len, line_len = early_bufs
         else:
-            grads, flat, offs, grad_len, line_len = _grad_buffers(named, n_rep)
+            grads, flat, offs, grad_len, line_len = _grad_buffers(named, n_rep, getattr(model, "_grad_store", None))
         model.grad_flat = flat[:grad_len]   # every gradient of this step, one contiguous buffer (parallel.py)
         if getattr(model, "grad_layout", None) is None or model.grad_layout[0] is not offs:
             model.grad_layout = (offs, grad_len)     # name -> offset (floats): parallel.gradient_support
@@ -189,8 +201,9 @@ def backward_launches(model, c, named, g_rgb, early_bufs=None, stage="all"):
                      ws.rgb_pre.data_ptr(), int(c['use_bg']), ws.rgb.data_ptr(), ws.grad_rgb.data_ptr(), C.byref(dg),
                      ws.ent_xyz.data_ptr() if binned else None, ws.ent_df.data_ptr() if binned else None, st)
         if binned:
-            if presorted:       # join the second stream (one cross-stream wait costs ~8 us of launch latency, so
-                # there is only this one: both sorts have long finished when march_backward ends)
+            if presorted:       # join the second stream.  One cross-stream wait costs ~10 us on the queue that waits, wherever
+                # it stands (placed behind tf_shade_backward, long after the sorts had finished, it cost the same), so
+                # there is only this one
                 torch.cuda.current_stream().wait_stream(c['sorted_on'])
             j = _bin_job(model, ws, "density", c['field'].density, c['field'].grid, 2 if presorted else 0, dg, ws.ent_df, 0)
             model._timed("tf_binned_scatter_density", lib.tf_binned_scatter, C.byref(j), st)

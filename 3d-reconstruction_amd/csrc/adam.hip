@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const TfAdamJob J) {
     const long long c0 = (long long)((int)blockIdx.x - (s_seg ? J.chunk_end[s_seg - 1] : 0)) * kChunk;
     const long long n = sg.n - c0 < kChunk ? sg.n - c0 : kChunk;
     float* __restrict__ p = sg.p + c0;
-    const float* __restrict__ g = sg.g + c0;
+    float* __restrict__ g = const_cast<float*>(sg.g) + c0;      // (written only with J.clear_grads)
     float* __restrict__ m = sg.m + c0;
     float* __restrict__ v = sg.v + c0;
     const double b1 = J.beta1, b2 = J.beta2, eps = J.eps;
@@ -77,9 +77,16 @@ __global__ __launch_bounds__(256) void adam_kernel(const TfAdamJob J) {
         *reinterpret_cast<tf::float4_t*>(p + 4 * i) = pv;
         *reinterpret_cast<tf::float4_t*>(m + 4 * i) = mv;
         *reinterpret_cast<tf::float4_t*>(v + 4 * i) = vv;
+        // consumed gradients go back to zero (lanes whose four are zero already write nothing; waves skipped above hold
+        // zeros only)
+        if (J.clear_grads && ((gv[0] != 0.f) | (gv[1] != 0.f) | (gv[2] != 0.f) | (gv[3] != 0.f)))
+            *reinterpret_cast<tf::float4_t*>(g + 4 * i) = (tf::float4_t){0.f, 0.f, 0.f, 0.f};
     }
     if (fresh && (tid & 63) == 0) atomicOr(J.touched + blockIdx.x, fresh);
-    for (long long i = 4 * n4 + tid; i < n; i += 256) upd(p[i], g[i], m[i], v[i]);
+    for (long long i = 4 * n4 + tid; i < n; i += 256) {
+        upd(p[i], g[i], m[i], v[i]);
+        if (J.clear_grads) g[i] = 0.f;
+    }
     // every workgroup has read *step by now or will have before it arrives here: the last one to arrive advances the
     // count for the next launch and re-arms the arrival counter (no separate "step += 1" launch per update)
     if (J.arrivals) {

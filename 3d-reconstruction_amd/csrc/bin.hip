@@ -105,7 +105,9 @@ __device__ __forceinline__ int key_groups(const KeyMap& K, int key) {
 constexpr int kItemKeyBits = 20;       // work item = key | group << 20  (TF_BIN_MAX_KEYS = 2^18 keys, <= 2^11 groups)
 
 // threads per workgroup and workgroups per entry shard of the count / fill passes (measured at config 2:
-// 1 / 2 / 4 / 8 / 16 slices -> count 23 / 15 / 12.5 / 15 / 22 us, fill 50 / 32 / 24 / 31 / 50 us; 1024 threads: no change)
+// 1 / 2 / 4 / 8 / 16 slices -> count 23 / 15 / 12.5 / 15 / 22 us, fill 50 / 32 / 24 / 31 / 50 us; 1024 threads: no change
+// alone, and beside tf_shade_forward — where these kernels only get the ~16 CU slots that kernel leaves — the fill pass takes
+// 50 us instead of 100 but the shading kernel 200 instead of 126: 0.750 ms per captured step against 0.706)
 constexpr int kSortThreads = 256;
 constexpr int kSlices = 4;   // workgroups per entry shard in the count / fill passes
 constexpr int kSortWgs = TF_N_SHARDS * kSlices;   // workgroups per job in the count / fill passes

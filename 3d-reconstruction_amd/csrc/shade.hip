@@ -104,7 +104,11 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
     // The list is dealt evenly in units of 16 samples (one MFMA sample tile): workgroup b owns tiles [b T / W, (b + 1) T / W)
     // of the T = ceil(total / 16) and walks them in chunks of <= 64; its last chunk is usually a partial one, and a partial
     // chunk costs its active sample tiles only (`nt` below).  (Dealt in whole 64-sample chunks, 1268 chunks on 512
-    // workgroups made three rounds of which the third was half empty: 2.48 chunk times of work took 3.)
+    // workgroups made three rounds of which the third was half empty: 2.48 chunk times of work took 3.  Handing a tail of
+    // the list — any share, up to all of it — out by a ticket taken one chunk ahead changed nothing beside the training
+    // step's sorts as they are, 0.714-0.725 ms per step against 0.714; and beside sorts with 1024-thread workgroups, which
+    // finish in half the time but starve the shading workgroup on their CU (this kernel: 200 us instead of 126), it
+    // recovered the loss only in part: 0.713 ms with everything by ticket, against 0.752 dealt evenly.)
     const long long n_tiles = (total + 15) / 16;
     const int v_begin = (int)(((long long)blockIdx.x * n_tiles) / (long long)gridDim.x) * 16;
     const int v_end = min(total, (int)((((long long)blockIdx.x + 1) * n_tiles) / (long long)gridDim.x) * 16);

@@ -201,8 +201,7 @@ class _Workspace:
                 nkeys, kpe = max(binned[0], binned[1]), binned[2]
                 n_ints = 4 * (nkeys + 8) + kpe * cap // 128 + 64      # work items: <= pairs / chunk + keys, chunk >= 256
                 # one sort workspace per job (density, appearance): both sorts run early, next to the shading kernels
-                spec += [("bin_status", 64, torch.int32),
-                         ("ent_xyz", cap * 3, torch.float32), ("ent_df", cap, torch.float32), ("ent_offset", R, torch.int32),
+                spec += [("ent_xyz", cap * 3, torch.float32), ("ent_df", cap, torch.float32), ("ent_offset", R, torch.int32),
                          ("binned", kpe * cap, torch.int32), ("bin_ints", n_ints, torch.int32),
                          ("binned_app", kpe * cap, torch.int32), ("bin_ints_app", n_ints, torch.int32)]
         if debug:
@@ -219,8 +218,8 @@ class _Workspace:
         self.hist_app = self.zero_block[n_ctr + n_hist[0]:]
         self.R, self.N, self.seg_cap, self.cap, self.words = R, N, seg_cap, cap, words
         self.save_valid, self.debug, self.binned_cfg = save_valid, debug, binned
-        if hasattr(self, "bin_status"):
-            self.bin_status.zero_()        # sticky error word of the binned scatter (TfBinJob.status)
+        self.bin_status = None             # sticky error word of the binned scatter (TfBinJob.status): the model's, set by
+        if hasattr(self, "bin_ints"):      # TensorBase._workspace (zeroing one here would be a launch in every captured step)
             self.bin_ints_len, self.binned_len = self.bin_ints.numel(), self.binned.numel()
         self.busy = False
         self.owner = None      # weakref to the autograd ctx that holds this (training) workspace until its backward
@@ -269,6 +268,8 @@ class TensorBase(nn.Module):
         # (C4 / C5: 7x the entries, +15-20 %): GraphedTrainStep switches it on from the measured sizes of its warm-up step
         self.early_sort = False
         self._sort_stream = None
+        self._bin_status = None
+        self._grad_store = None      # graph.GraphedTrainStep: the gradient buffer its steps share (autograd._grad_buffers)
         # tf_shade_forward workgroups (of 512 CU slots) while the early sorts run next to it; the sort kernels need a CU
         # slot's LDS and registers (measured at config 2 with the 16-sample work split: 384 / 448 / 480 / 496 / 504 / 512 workgroups ->
         # 0.759 / 0.737 / 0.734 / 0.732 / 0.731 / 0.736 ms per step)
@@ -480,7 +481,7 @@ class TensorBase(nn.Module):
 
     # ---- cached launch descriptors for the common call (no FreeNeRF masks) --------------------------------------
     class _Plan:
-        __slots__ = ("key", "field", "shade", "keep", "job", "watch")
+        __slots__ = ("key", "dev", "ptrs", "field", "shade", "keep", "job", "watch")
 
     def _plan(self, train, dev):
         """TfField / TfShade / the weight-pack job of a forward without masks, built once and reused until the alpha
@@ -488,18 +489,27 @@ class TensorBase(nn.Module):
         eager train step spent 0.25 ms of host time per call rebuilding these ctypes structs (round-1 verdict #10)."""
         named = self._named_cache
         params = named[1] if named is not None else list(self.parameters())
-        key = (self.alphaMask, self._geom, dev) + tuple(params)
+        key = (self.alphaMask, self._geom) + tuple(params)
         pl = self._plans.get(train)
-        if pl is not None and self._geom is not None and len(pl.key) == len(key) and all(a is b for a, b in zip(pl.key, key)):
+        # (tensor.device hands out a new object per access: compared by value, everything else by identity)
+        if pl is not None and self._geom is not None and pl.dev == dev and len(pl.key) == len(key) \
+                and all(a is b for a, b in zip(pl.key, key)) and pl.ptrs == self._plan_values(params):
             return pl
         pl = TensorBase._Plan()
         pl.field = self._field_desc([None, None, None])
         shade, keep = self._shade_desc([None, None, None], None, dev, train=train, pack=True, zero=None, job_out=pl)
         pl.shade, pl.keep = shade, keep
         params = self._named_cache[1] if self._named_cache is not None else list(self.parameters())
-        pl.key = (self.alphaMask, self._geom, dev) + tuple(params)
+        pl.key, pl.dev, pl.ptrs = (self.alphaMask, self._geom) + tuple(params), dev, self._plan_values(params)
         self._plans[train] = pl
         return pl
+
+    def _plan_values(self, params):
+        """What a plan's descriptors hold by value: the parameters' addresses (`p.data = ...` re-homes a parameter without
+        replacing the object) and the scalar settings a caller may assign."""
+        return [p.data_ptr() for p in params] + [float(self.near_far[0]), float(self.near_far[1]), float(self.distance_scale),
+                                                 float(self.density_shift), float(self.rayMarch_weight_thres),
+                                                 self.fea2denseAct]
 
     def _refresh_packed(self, pl, zero):
         """One tf_pack_matrices launch when a watched weight changed (every training step) — the forward's zero block
@@ -691,6 +701,10 @@ class TensorBase(nn.Module):
                 extra = (self._n_app_total(), wslab, (int(sh.in_c) + 15) // 16 * 16 if mlp_head else 0,
                          int(sh.feature_c) if mlp_head else 0)
             ws = _Workspace(R, N, dev, save_valid, self._debug_masks, binned, extra)
+            if binned is not None:
+                if self._bin_status is None or self._bin_status.device != dev:
+                    self._bin_status = torch.zeros(64, dtype=torch.int32, device=dev)
+                ws.bin_status = self._bin_status
             if not save_valid:
                 self._ws_cache = {key: ws}
             elif not torch.cuda.is_current_stream_capturing():
@@ -780,6 +794,9 @@ class TensorBase(nn.Module):
             io.dbg_app_bits = ws.dbg_app.data_ptr()
             io.dbg_z = ws.dbg_z.data_ptr()
         self._timed("tf_march_forward", lib.tf_march_forward, C.byref(field), C.byref(io), st)
+        # (the sorts are issued BEFORE the shading launch: issued behind it, tf_shade_forward follows the march kernel on the
+        # same queue and runs alone — 116 us instead of 127 — but the first sort kernel then finds every CU slot taken and the
+        # sorts finish behind the forward: 0.737 ms per captured step against 0.714)
         sorted_on = after_march(ws, field, shade) if early else None
         save = None
         if save_valid and shade.head == H.HEAD_MLP:      # rows the backward streams back instead of recomputing them
@@ -817,18 +834,17 @@ class TensorBase(nn.Module):
         return ctx['rgb_map'], ctx['depth'], num_valid
 
     def check_scatter_status(self):
-        """Raises if a binned-scatter kernel of this model's training workspaces ever refused an out-of-range position
-        (TfBinJob.status; one small D2H copy and a stream sync per workspace: call it at logging points, not per step)."""
-        for pool in self._train_ws.values():
-            for ws in pool:
-                if ws.binned_cfg is None:
-                    continue
-                bits = C.c_int(0)
-                rc = H.lib().tf_bin_status(ws.bin_status.data_ptr(), C.byref(bits), _stream())
-                if rc != 0:
-                    raise H.HipError(f"tf_binned_scatter refused out-of-range positions (status bits {bits.value}: 1 = sorted "
-                                     f"position outside binned[], 2 = work-item table overflow, 4 = entry index outside "
-                                     f"the list): the key histogram did not describe the entries")
+        """Raises if a binned-scatter kernel of this model's training steps (eager or captured) ever refused an out-of-range
+        position (TfBinJob.status, one sticky word per model; one small D2H copy and a stream sync: call it at logging
+        points, not per step)."""
+        if self._bin_status is None:
+            return
+        bits = C.c_int(0)
+        rc = H.lib().tf_bin_status(self._bin_status.data_ptr(), C.byref(bits), _stream())
+        if rc != 0:
+            raise H.HipError(f"tf_binned_scatter refused out-of-range positions (status bits {bits.value}: 1 = sorted "
+                             f"position outside binned[], 2 = work-item table overflow, 4 = entry index outside "
+                             f"the list): the key histogram did not describe the entries")
 
     # ---- public feature hooks (used by compute_alpha in the reference) --------------------------
     def compute_densityfeature(self, xyz_sampled, mask=None):

@@ -57,6 +57,9 @@ class GraphedTrainStep:
         self.loss = torch.zeros((), device=dev)
         self._grad_rgb = torch.zeros(batch, 3, device=dev)
         self._loss_state = torch.zeros(2, device=dev)      # tf_composite_forward_loss: running sum + arrival counter
+        # the step's gradient buffer, kept across steps when the optimizer is a FusedAdam: its launch returns every gradient
+        # it consumed to zero (consume_grads), so the backward accumulates into the same buffer again without a fill
+        self._gstore = {'flat': None, 'clean': True}
         self.n_samples, self.mask, self.ndc = n_samples, mask, ndc_ray
         # white_bg=False (datasets without a white background, e.g. llff.py:141): the reference adds the white
         # background to a training batch with probability 1/2 (tensorBase.py:380) — a host decision per step, so the
@@ -98,14 +101,19 @@ class GraphedTrainStep:
         # loss = mean((rgb - target)^2) (train.py:334) and d loss / d rgb are formed by the compositing launch itself
         # (tf_composite_forward_loss): no launch of their own between the forward and the backward
         model._loss_fuse = self._fuse(1.0 / self._world if self.split else 1.0)
+        model._grad_store = self._store()
         try:
             rgb, _, _ = model(self.rays, self.mask, white_bg=self.white_bg, is_train=True, ndc_ray=self.ndc,
                               N_samples=self.n_samples)
+            model._loss_fuse = None
+            self.opt.zero_grad(set_to_none=True)
+            rgb.backward(self._grad_rgb)
         finally:
             model.count_samples = keep
-            model._loss_fuse = None
-        self.opt.zero_grad(set_to_none=True)
-        rgb.backward(self._grad_rgb)
+            model._loss_fuse = model._grad_store = None
+
+    def _store(self):
+        return self._gstore if hasattr(self.opt, "consume_grads") else None
 
     def _fuse(self, grad_scale):
         """TfLossFuse of this step's static buffers (target, gradient, loss, the kernel's two state words)."""
@@ -134,6 +142,7 @@ class GraphedTrainStep:
         keep, model.count_samples = model.count_samples, False
         hook, model._density_grads_ready = getattr(model, "_density_grads_ready", None), None   # no collective in a capture
         model._loss_fuse = self._fuse(1.0 / self._world)
+        model._grad_store = self._store()
         try:
             with torch.no_grad():
                 c = model._run_forward(self.rays, self.mask, self.white_bg, True, self.ndc, self.n_samples, save_valid=True,
@@ -145,7 +154,7 @@ class GraphedTrainStep:
         finally:
             model.count_samples = keep
             model._density_grads_ready = hook
-            model._loss_fuse = None
+            model._loss_fuse = model._grad_store = None
         for n, p in named:
             p.grad = grads[n]
         self._ctx = (c, named)
@@ -159,7 +168,17 @@ class GraphedTrainStep:
         if self._regw is not None:      # rank-invariant terms: added after the data gradients have been reduced
             from .regularizers import add_regularizer_grads_
             add_regularizer_grads_(self.model, 1.0, 1.0, 1.0, 1.0, weights_dev=self._regw)
-        self.opt.step()
+        # (the buffer was handed out by this step's backward: not clean, and p.grad are views of it)
+        consume = self._store() is not None and self._gstore['flat'] is not None and not self._gstore['clean']
+        if not consume:
+            self.opt.step()
+            return
+        keep, self.opt.consume_grads = self.opt.consume_grads, True
+        try:
+            self.opt.step()
+        finally:
+            self.opt.consume_grads = keep
+        self._gstore['clean'] = True
 
     def _body(self):
         if self.split:      # the eager warm-up runs the very sequence the three graphs will replay

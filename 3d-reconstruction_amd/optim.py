@@ -35,6 +35,9 @@ class FusedAdam(torch.optim.Optimizer):
         self._jobs = None        # cached TfAdamJob structs (only the gradient pointers change from step to step)
         self._lr_host = None
         self._lr_dev = self._step_dev = None
+        # True: step() also returns every gradient it consumed to zero (TfAdamJob.clear_grads) — zero_grad() folded into the
+        # update for callers that accumulate the next step's gradients into the same buffer (graph.GraphedTrainStep)
+        self.consume_grads = False
 
     def _params(self):
         return [(gi, p) for gi, g in enumerate(self.param_groups) for p in g['params']]
@@ -157,6 +160,7 @@ class FusedAdam(torch.optim.Optimizer):
                         raise H.HipError("FusedAdam: a parameter's storage was replaced; build a new optimizer")
                     job.seg[i].g = g.data_ptr()
                 job._memo = (base, span, g0.stride(), g1.stride()) if len(part) > 1 else None
+            job.clear_grads = int(bool(self.consume_grads))
             H.check(lib.tf_adam_step(C.byref(job), st), "tf_adam_step")
         if not one_launch:
             self._step_dev += 1

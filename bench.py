@@ -89,6 +89,11 @@ def build_scene(recon, dev, grid, views, seed=0):
     aabb = torch.tensor(S.LEGO_AABB, device=dev)
     reso = recon.N_to_reso(grid ** 3, aabb)
     model = recon.TensorVMSplit(S.lego_args(), aabb, reso, S.LEGO_NEAR_FAR, dev)
+    for kv in filter(None, os.environ.get("TF_BENCH_SET", "").split(",")):     # tuning runs: model attribute overrides
+        k, v = kv.split("=")
+        if not hasattr(model, k):
+            raise SystemExit(f"TF_BENCH_SET: the model has no attribute {k!r}")
+        setattr(model, k, type(getattr(model, k))(int(v)))
     S.make_trained_like(model, recon.AlphaGridMask)
     n_samples = min(int(1e6), recon.cal_n_samples(reso, 0.5))        # train.py:208
     rays = S.blender_rays(views)

@@ -428,7 +428,9 @@ typedef struct TfAdamSeg {
 } TfAdamSeg;
 typedef struct TfAdamJob {
     int n_seg;
-    int pad_;
+    int clear_grads;          /* 1: every non-zero gradient element is set to zero once it has been consumed (the g pointers
+                               * are written through): the buffer is all zeros again when the launch ends, so the next
+                               * backward can accumulate into it without a fill of its own (graph.GraphedTrainStep) */
     TfAdamSeg seg[TF_ADAM_MAX_SEG];
     int chunk_end[TF_ADAM_MAX_SEG];
     const float* lrs;

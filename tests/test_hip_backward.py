@@ -255,6 +255,39 @@ def test_fused_adam_untouched_regions_and_state_restore(recon):
 
 
 @pytest.mark.gpu
+def test_fused_adam_returns_consumed_gradients_to_zero(recon):
+    """FusedAdam.consume_grads (TfAdamJob.clear_grads): the update is the same, and the gradient buffer is all zeros when the
+    launch ends — what lets GraphedTrainStep accumulate every step's gradients into one buffer without a fill."""
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    shape = (1, 16, 97, 53)          # 82,256 floats: ten whole 8192-chunks and a ragged tail
+    pa = torch.nn.Parameter(recon.channel_last_param(torch.randn(*shape)).data.to(dev))
+    pb = torch.nn.Parameter(pa.detach().clone())
+    qa, qb = torch.nn.Parameter(torch.randn(131, device=dev)), None      # a second, odd-sized segment
+    qb = torch.nn.Parameter(qa.detach().clone())
+    oa = recon.FusedAdam([pa, qa], lr=0.02, betas=(0.9, 0.99))
+    ob = recon.FusedAdam([pb, qb], lr=0.02, betas=(0.9, 0.99))
+    ob.consume_grads = True
+    g = torch.Generator().manual_seed(1)
+    gb, hb = torch.zeros_like(pb), torch.zeros_like(qb)     # the consumer's buffers live across the steps
+    pb.grad, qb.grad = gb, hb
+    for it in range(4):
+        gr = torch.randn(*shape, generator=g).to(dev)
+        live = torch.zeros(97, dtype=torch.bool, device=dev)
+        live[5 * it: 30 + 15 * it] = True
+        gr = gr * live[None, None, :, None]
+        hr = torch.randn(131, generator=g).to(dev)
+        pa.grad, qa.grad = torch.empty_like(pa).copy_(gr), hr.clone()
+        gb += gr                                            # accumulate into the (zero) buffers, as the backward does
+        hb += hr
+        oa.step()
+        ob.step()
+        assert int(torch.count_nonzero(gb)) == 0 and int(torch.count_nonzero(hb)) == 0
+        assert int(torch.count_nonzero(pa.grad)) > 0        # the default leaves the gradients alone
+        assert torch.equal(pa, pb) and torch.equal(qa, qb)
+
+
+@pytest.mark.gpu
 def test_graphed_step_with_ndc_rays(recon):
     """Forward-facing configuration (BASELINE config 4) through the captured step: the NDC jitter is a device-side
     draw (tensorBase.py:183-184), which must keep advancing under graph replay."""

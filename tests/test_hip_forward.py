@@ -195,3 +195,40 @@ def test_early_ray_termination_skips_work_on_an_opaque_scene(recon):
     assert res[1e-7][3] < res[0.0][3], (res[1e-7][3], res[0.0][3])      # (the cut acts per block of 64 density samples)
     assert (res[1e-7][0] - res[0.0][0]).abs().max().item() < 1e-5
     assert ((res[1e-7][1] - res[0.0][1]).abs() / res[0.0][1].abs().clamp_min(1e-3)).max().item() < 1e-4
+
+
+@pytest.mark.gpu
+def test_cached_launch_descriptors_are_reused_and_follow_the_parameters(recon):
+    """The forward's TfField / TfShade / pack job are built once (TensorBase._plan) and reused while nothing they hold by
+    value changed: a second call must not rebuild them, and a parameter that is re-homed (`p.data = ...`),
+    updated in place, or a changed scalar setting must be seen by the next call."""
+    c = Case("vm_head_MLP")
+    model = build_model(recon, c, "cuda:0")
+    rays = c.rays.cuda()
+    with torch.no_grad():
+        rgb0, depth0, _ = model(rays, None)
+        plan = model._plans[False]
+        rgb1, _, _ = model(rays, None)
+        assert model._plans[False] is plan and torch.equal(rgb0, rgb1)
+        # in-place update of a shading weight (what an optimiser step does): same plan, new packed copy
+        w = model.renderModule.mlp[0].weight
+        w.mul_(0.5)
+        twin = build_model(recon, c, "cuda:0")
+        twin.renderModule.mlp[0].weight.mul_(0.5)
+        want, _, _ = twin(rays, None)
+        got, _, _ = model(rays, None)
+        assert model._plans[False] is plan and torch.equal(got, want)
+        # re-homed factor: same Parameter object, new storage with new values
+        p = model.density_plane[0]
+        p.data = (p.data * 1.25).clone()
+        twin.density_plane[0].mul_(1.25)
+        want, want_d, _ = twin(rays, None)
+        got, got_d, _ = model(rays, None)
+        assert model._plans[False] is not plan
+        assert torch.equal(got, want) and torch.equal(got_d, want_d)
+        # a scalar the descriptors hold by value
+        plan = model._plans[False]
+        model.distance_scale = twin.distance_scale = 10.0
+        want, _, _ = twin(rays, None)
+        got, _, _ = model(rays, None)
+        assert model._plans[False] is not plan and torch.equal(got, want)
