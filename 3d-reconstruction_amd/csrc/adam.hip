@@ -46,41 +46,60 @@ __global__ __launch_bounds__(256) void adam_kernel(const TfAdamJob J) {
     const long long n4 = n >> 2;
     // `touched` (one word per workgroup): bit (8 * wave + round) is set once the 256 floats that wave handles in that
     // round have seen a non-zero gradient.  While it is clear their moments are still the zeros they were created
-    // with, so only the gradient is read (1 of the 3 input streams); texels no sample ever reaches stay that way.
+    // with, so only the gradient is read (1 of the 4 input streams); texels no sample ever reaches stay that way.
+    // The 8 rounds of a thread go in two batches of 4 whose loads are all requested before the first is used (one round at
+    // a time the kernel was a chain of 2 dependent memory latencies per round: 47 us at config 2 for ~130 MB of traffic).
     const int wave = tid >> 6;
     const unsigned seen = J.touched ? J.touched[blockIdx.x] : 0xFFFFFFFFu;
     unsigned fresh = 0;
-    int round = 0;
-#pragma unroll 2
-    for (long long i = tid; i < n4; i += 256, ++round) {
-        const unsigned bit = 1u << (8 * wave + round);
-        tf::float4_t mv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-        if (seen & bit) {
-            mv = tf::ld4(m + 4 * i);
-            vv = tf::ld4(v + 4 * i);
+    constexpr int kBatch = 4;
+    static_assert(kChunk == 256 * 4 * 2 * kBatch, "two batches of kBatch rounds of 256 lanes x 4 floats");
+    const tf::float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int b0 = 0; b0 < 2 * kBatch; b0 += kBatch) {
+        tf::float4_t gv[kBatch], mv[kBatch], vv[kBatch], pv[kBatch];
+#pragma unroll
+        for (int r = 0; r < kBatch; ++r) {      // every load whose need is known up front
+            const long long i = tid + 256LL * (b0 + r);
+            const bool in = i < n4, old = (seen >> (8 * wave + b0 + r)) & 1u;
+            gv[r] = in ? tf::ld4(g + 4 * i) : zero4;
+            mv[r] = in && old ? tf::ld4(m + 4 * i) : zero4;
+            vv[r] = in && old ? tf::ld4(v + 4 * i) : zero4;
+            pv[r] = in && old ? tf::ld4(p + 4 * i) : zero4;
         }
-        const tf::float4_t gv = tf::ld4(g + 4 * i);
         // Entries whose gradient and both moments are zero stay exactly as they are (m = v = 0, update 0 / (0 + eps)):
         // a wave that holds only such entries neither reads the parameters nor writes anything back, which is exact.
-        bool live = false;
+        bool live[kBatch];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) live |= (gv[e] != 0.f) | (mv[e] != 0.f) | (vv[e] != 0.f);
-        if (!__any(live)) continue;
-        fresh |= bit & ~seen;
-        tf::float4_t pv = tf::ld4(p + 4 * i);
+        for (int r = 0; r < kBatch; ++r) {
+            bool l = false;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float pe = pv[e], me = mv[e], ve = vv[e];
-            upd(pe, gv[e], me, ve);
-            pv[e] = pe; mv[e] = me; vv[e] = ve;
+            for (int e = 0; e < 4; ++e) l |= (gv[r][e] != 0.f) | (mv[r][e] != 0.f) | (vv[r][e] != 0.f);
+            live[r] = __any(l);
+            const long long i = tid + 256LL * (b0 + r);
+            const bool old = (seen >> (8 * wave + b0 + r)) & 1u;
+            if (live[r] && !old && i < n4) pv[r] = tf::ld4(p + 4 * i);     // first gradient of this piece: its parameters
         }
-        *reinterpret_cast<tf::float4_t*>(p + 4 * i) = pv;
-        *reinterpret_cast<tf::float4_t*>(m + 4 * i) = mv;
-        *reinterpret_cast<tf::float4_t*>(v + 4 * i) = vv;
-        // consumed gradients go back to zero (lanes whose four are zero already write nothing; waves skipped above hold
-        // zeros only)
-        if (J.clear_grads && ((gv[0] != 0.f) | (gv[1] != 0.f) | (gv[2] != 0.f) | (gv[3] != 0.f)))
-            *reinterpret_cast<tf::float4_t*>(g + 4 * i) = (tf::float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < kBatch; ++r) {
+            const long long i = tid + 256LL * (b0 + r);
+            if (!live[r] || i >= n4) continue;
+            fresh |= (1u << (8 * wave + b0 + r)) & ~seen;
+            tf::float4_t pq = pv[r], mq = mv[r], vq = vv[r];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pe = pq[e], me = mq[e], ve = vq[e];
+                upd(pe, gv[r][e], me, ve);
+                pq[e] = pe; mq[e] = me; vq[e] = ve;
+            }
+            *reinterpret_cast<tf::float4_t*>(p + 4 * i) = pq;
+            *reinterpret_cast<tf::float4_t*>(m + 4 * i) = mq;
+            *reinterpret_cast<tf::float4_t*>(v + 4 * i) = vq;
+            // consumed gradients go back to zero (lanes whose four are zero already write nothing; waves skipped above
+            // hold zeros only)
+            if (J.clear_grads && ((gv[r][0] != 0.f) | (gv[r][1] != 0.f) | (gv[r][2] != 0.f) | (gv[r][3] != 0.f)))
+                *reinterpret_cast<tf::float4_t*>(g + 4 * i) = zero4;
+        }
     }
     if (fresh && (tid & 63) == 0) atomicOr(J.touched + blockIdx.x, fresh);
     for (long long i = 4 * n4 + tid; i < n; i += 256) {
