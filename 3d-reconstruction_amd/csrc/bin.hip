@@ -355,8 +355,10 @@ __device__ __forceinline__ float entry_grad(const TfBinJob& J, int e, int ch) {
 __device__ __forceinline__ int rl(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
 __device__ __forceinline__ float rlf(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
 
-// entries a wave stages per round (LDS per wave: ER x (C + 8) floats)
-__host__ __device__ inline int entries_per_round(int cmax) { return cmax <= 16 ? 32 : 16; }
+// entries a wave stages per round (LDS per wave: ER x (C + 8) floats).  16: with 32 the staging rows put a workgroup at
+// 33 KB of LDS, four per CU; at 27 KB and 96 VGPRs five fit (20 waves per CU to hide the stage's gathers behind):
+// 0.706 -> 0.694 ms per captured step at config 2
+__host__ __device__ inline int entries_per_round(int cmax) { (void)cmax; return 16; }
 __host__ __device__ inline int lane_group(int c) { return c <= 16 ? 16 : (c <= 32 ? 32 : 64); }
 
 // K4.  Work item = <= chunk entries of one key.  Per round each wave stages ER entries:
@@ -368,7 +370,7 @@ __host__ __device__ inline int lane_group(int c) { return c <= 16 ? 16 : (c <= 3
 //          accumulation block (LDS float atomics measured ~100 cycles per wave-instruction, a plain RMW is 3 short
 //          LDS ops; lanes of one instruction never collide and the LDS pipe is in order).  No global access.
 //   The four private blocks are summed when the work item is flushed.
-__global__ __launch_bounds__(256, 4) void bin_scatter_kernel(const TfBinJob J, const KeyMap K, int ER, int cmax) {
+__global__ __launch_bounds__(256, 5) void bin_scatter_kernel(const TfBinJob J, const KeyMap K, int ER, int cmax) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wstride = ER * (cmax + 8);
     int total = J.chunk_off[K.nkeys];
@@ -382,7 +384,8 @@ __global__ __launch_bounds__(256, 4) void bin_scatter_kernel(const TfBinJob J, c
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
         TF_MARK(7);
         // per-thread coordinates from an opaque copy of the thread id: nothing derived from it is hoisted out of the
-        // work-item loop, which keeps the kernel at 5 waves per SIMD without scratch
+        // work-item loop, which keeps the kernel at 5 waves per SIMD (96 VGPRs; 5 dwords of it live in scratch, four of
+        // them touched once per work item, one once per round)
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const int wave = tid >> 6, lane = tid & 63;
@@ -436,8 +439,8 @@ __global__ __launch_bounds__(256, 4) void bin_scatter_kernel(const TfBinJob J, c
         const int ja = i == 0 ? 1 : 0, jb = i == 2 ? 1 : 2;     // CP: the other two line tensors
         const int T1 = K.T + 1;
         const int nblk = is_line ? (K.LB + 1) * C : T1 * T1 * C;
-        for (int q = tid; q < 4 * nblk; q += 256) blk0[q] = 0.f;
         float* blk = blk0 + wave * nblk;
+        for (int q = lane; q < nblk; q += 64) blk[q] = 0.f;       // (the previous item's flush ended in a barrier)
         const int W = J.grid[mat0(i)], Hh = J.grid[mat1(i)], Gl = J.grid[vecm(i)];
         const int tyb = is_line ? 0 : (local / K.ntx[i]) * K.T, txb = is_line ? 0 : (local % K.ntx[i]) * K.T;
         const int lb0 = is_line ? local * K.LB : 0;
@@ -448,17 +451,17 @@ __global__ __launch_bounds__(256, 4) void bin_scatter_kernel(const TfBinJob J, c
         // depends on ONE level of random global loads (factor taps + gradient piece) instead of three in a chain
         // (index -> coordinates -> taps).
         const int LPE = 64 / ER, ent = lane / LPE, sub = lane - ent * LPE;
+        // (an index is validated where it is first used, a round later: a check here would wait for the load it follows)
         auto idx_of = [&](int rd) {
             const int b = beg + (rd * 4 + wave) * ER + ent;
-            int e = (rd < rounds && b < end) ? J.binned[b] : -1;
-            if (e >= entry_cap) {       // not an entry of this list: skip it, keep the evidence
-                flag(J, TF_BIN_ERR_ENTRY);
-                e = -1;
-            }
-            return e;
+            return (rd < rounds && b < end) ? J.binned[b] : -1;
         };
         int e_cur = idx_of(0), e_nxt = idx_of(1);
         float u_cur[3] = {0.f, 0.f, 0.f};
+        if (e_cur >= entry_cap) {       // not an entry of this list: skip it, keep the evidence
+            flag(J, TF_BIN_ERR_ENTRY);
+            e_cur = -1;
+        }
         if (e_cur >= 0) {
             u_cur[0] = J.xyz[(size_t)e_cur * 3]; u_cur[1] = J.xyz[(size_t)e_cur * 3 + 1]; u_cur[2] = J.xyz[(size_t)e_cur * 3 + 2];
         }
@@ -467,10 +470,18 @@ __global__ __launch_bounds__(256, 4) void bin_scatter_kernel(const TfBinJob J, c
             const int nk = max(0, min(ER, end - base));
             const int e_far = idx_of(rd + 2);
             float u_nxt[3] = {0.f, 0.f, 0.f};
+            if (e_nxt >= entry_cap) {
+                flag(J, TF_BIN_ERR_ENTRY);
+                e_nxt = -1;
+            }
             if (e_nxt >= 0) {
                 u_nxt[0] = J.xyz[(size_t)e_nxt * 3]; u_nxt[1] = J.xyz[(size_t)e_nxt * 3 + 1]; u_nxt[2] = J.xyz[(size_t)e_nxt * 3 + 2];
             }
-            __syncthreads();                         // blk zeroed / previous round's staging consumed
+            // No workgroup barrier inside the rounds: the staging rows, the meta rows and the accumulation block are this
+            // wave's own, and a wave's LDS operations execute in order — the four waves drift apart and fill each other's
+            // memory waits instead of meeting twice per round.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             TF_MARK(1);
             // ---------------- stage: LPE = 64 / ER lanes per entry, lane `sub` takes channel quads sub, sub+LPE, ...
             if (ent < nk && e_cur < 0) {     // a rejected entry contributes nothing
@@ -538,7 +549,8 @@ __global__ __launch_bounds__(256, 4) void bin_scatter_kernel(const TfBinJob J, c
                     }
                 }
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             TF_MARK(2);
             // ---------------- accumulate (private block, plain read-add-write)
             const int nfoot = is_line ? 2 * C : 4 * C;
@@ -684,7 +696,9 @@ int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream) {
     const size_t sc_bytes = 4 * (blk_bytes > lblk_bytes ? blk_bytes : lblk_bytes) + (size_t)4 * ER * (cmax + 8) * 4;
     if (sc_bytes > 150 * 1024) return (int)hipErrorInvalidValue;
     int per_cu = (int)((160 * 1024) / (sc_bytes + 512));
-    per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
+    // (never more workgroups than are resident at once — 5 per CU by registers: the items are dealt by a fixed stride, and
+    // workgroups that start when the first ones finish double the kernel's time)
+    per_cu = per_cu > 5 ? 5 : (per_cu < 1 ? 1 : per_cu);
     if (job->stage < 0 || job->stage > 2) return (int)hipErrorInvalidValue;
     if (job->stage != 2) {
         const TfBinJob* const jobs[2] = {job, nullptr};
