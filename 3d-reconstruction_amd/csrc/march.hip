@@ -52,7 +52,8 @@ __global__ __launch_bounds__(64) void march_forward_kernel(const TfField F, cons
     const int ncap = (N + 63) & ~63;
     float* wq = smem;                                  // staged weights of shaded samples
     float* fbuf = smem + ncap;                         // density features of the current 64 entries
-    uint16_t* q = reinterpret_cast<uint16_t*>(fbuf + 64);  // compacted sample indices
+    uint16_t* q = reinterpret_cast<uint16_t*>(fbuf + 64);  // compacted sample indices (the density samples, in ray order)
+    uint16_t* qs = q + ncap;                               // ... of the shaded ones
 
     const int lane = threadIdx.x;
     const int r = xcd_remap(blockIdx.x, gridDim.x);
@@ -86,26 +87,48 @@ __global__ __launch_bounds__(64) void march_forward_kernel(const TfField F, cons
             if (io.dbg_valid_bits) io.dbg_valid_bits[(size_t)r * words + wd] = 0;
         }
     int cnt = 0, nbbox = 0;
-    for (int base = 0; base < n_walk; base += 64) {
-        const int i = base + lane;
-        bool inb = false, val = false;
-        if (i < n_walk) {
-            float z = sample_z(F, ray, ztab, i);
-            float p[3];
-            sample_pos(ray, z, p);
-            inb = in_bbox(F, p);
-            val = inb && (F.alpha_cells == nullptr || alpha_hit(F, p));
+    TF_T0();
+    // Four blocks of 64 slots per trip: their alpha-cell loads are requested together (one block per trip made the walk a
+    // chain of ~9 dependent memory latencies: 64 % of a wave's time in this kernel at config 2).
+    constexpr int U = 4;
+    for (int base = 0; base < n_walk; base += 64 * U) {
+        bool inb[U], chk[U];
+        size_t cell[U];
+        uint32_t allow[U], m[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + 64 * u + lane;
+            inb[u] = chk[u] = false;
+            cell[u] = 0;
+            allow[u] = 0;
+            if (i < n_walk) {
+                float z = sample_z(F, ray, ztab, i);
+                float p[3];
+                sample_pos(ray, z, p);
+                inb[u] = in_bbox(F, p);
+                if (inb[u] && F.alpha_cells) chk[u] = alpha_cell(F, p, cell[u], allow[u]);
+            }
         }
-        const uint64_t mb = __ballot(inb), mv = __ballot(val);
-        if (lane == 0) {
-            if (io.dbg_bbox_bits) io.dbg_bbox_bits[(size_t)r * words + (base >> 6)] = mb;
-            if (io.dbg_valid_bits) io.dbg_valid_bits[(size_t)r * words + (base >> 6)] = mv;
+        if (F.alpha_cells) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) m[u] = F.alpha_cells[cell[u]];      // (cell 0 for the slots that need none)
         }
-        if (val) q[cnt + prefix_popc(mv)] = (uint16_t)i;
-        cnt += __popcll(mv);
-        nbbox += __popcll(mb);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (base + 64 * u >= n_walk) break;                            // wave-uniform
+            const bool val = inb[u] && (F.alpha_cells == nullptr || (chk[u] && (m[u] & allow[u]) != 0));
+            const uint64_t mb = __ballot(inb[u]), mv = __ballot(val);
+            if (lane == 0) {
+                if (io.dbg_bbox_bits) io.dbg_bbox_bits[(size_t)r * words + ((base >> 6) + u)] = mb;
+                if (io.dbg_valid_bits) io.dbg_valid_bits[(size_t)r * words + ((base >> 6) + u)] = mv;
+            }
+            if (val) q[cnt + prefix_popc(mv)] = (uint16_t)(base + 64 * u + lane);
+            cnt += __popcll(mv);
+            nbbox += __popcll(mb);
+        }
     }
     __syncthreads();
+    TF_MARK(0);
 
     // ---------------- phases B + C over the compacted queue
     float T = 1.f, acc_l = 0.f, dep_l = 0.f;
@@ -127,6 +150,7 @@ __global__ __launch_bounds__(64) void march_forward_kernel(const TfField F, cons
             if ((lane & 3) == 0) fbuf[s * 16 + (lane >> 2)] = f;
         }
         __syncthreads();
+        TF_MARK(1);
 
         const int slot = kb + lane;
         const bool act = slot < cnt;
@@ -154,8 +178,8 @@ __global__ __launch_bounds__(64) void march_forward_kernel(const TfField F, cons
         const bool shade = act && (w > F.weight_thres);       // tensorBase.py:370
         const uint64_t ms = __ballot(shade);
         if (shade) {
-            const int j = appcnt + prefix_popc(ms);           // j <= slot: that queue entry is already consumed
-            q[j] = (uint16_t)idx;
+            const int j = appcnt + prefix_popc(ms);
+            qs[j] = (uint16_t)idx;
             wq[j] = w;
             if (io.dbg_app_bits)
                 atomicOr(reinterpret_cast<unsigned*>(io.dbg_app_bits) + (size_t)r * words * 2 + (idx >> 5),
@@ -168,6 +192,7 @@ __global__ __launch_bounds__(64) void march_forward_kernel(const TfField F, cons
         }
         done = min(cnt, kb + 64);
         __syncthreads();
+        TF_MARK(2);
         if (T < io.t_stop) break;                             // wave-uniform
     }
 
@@ -175,11 +200,15 @@ __global__ __launch_bounds__(64) void march_forward_kernel(const TfField F, cons
     const float acc = wave_sum(acc_l);
     float dep = wave_sum(dep_l);
     dep = dep + (1.f - acc) * io.rays[(size_t)r * 6 + 5];     // tensorBase.py:388 (last ray column, d_z)
-    int base = 0;
+    int base = 0, eb = 0;
     if (lane == 0) {
         int* ctr = io.counters + shard * kShardStride;
         const int seg_cap = ((gridDim.x + kShards - 1) / kShards) * N;
-        base = shard * seg_cap + (appcnt ? atomicAdd(&ctr[0], appcnt) : 0);
+        // the two reservations are requested together (one after the other they were two memory round trips in a row)
+        const int a0 = appcnt ? atomicAdd(&ctr[0], appcnt) : 0;
+        const int a3 = (io.ent_xyz && done) ? atomicAdd(&ctr[3], done) : 0;
+        base = shard * seg_cap + a0;
+        eb = shard * seg_cap + a3;
         atomicAdd(&ctr[1], done);
         atomicAdd(&ctr[2], nbbox);
         io.acc[r] = acc;
@@ -187,19 +216,13 @@ __global__ __launch_bounds__(64) void march_forward_kernel(const TfField F, cons
         io.app_offset[r] = base;
         io.app_count[r] = appcnt;
         io.val_count[r] = done;
+        if (io.ent_xyz) io.ent_offset[r] = eb;
     }
     if (io.ent_xyz) {      // density entry list of the binned backward scatter: coordinates now, dL/df in the backward
-        __syncthreads();   // val_idx was written by other lanes of this wave
-        int eb = 0;
-        if (lane == 0) {
-            const int seg_cap = ((gridDim.x + kShards - 1) / kShards) * N;
-            eb = shard * seg_cap + (done ? atomicAdd(&io.counters[shard * kShardStride + 3], done) : 0);
-            io.ent_offset[r] = eb;
-        }
         eb = __shfl(eb, 0, 64);
         for (int k = lane; k < done; k += 64) {
             float p[3], u[3];
-            sample_pos(ray, sample_z(F, ray, ztab, io.val_idx[vbase + k]), p);
+            sample_pos(ray, sample_z(F, ray, ztab, q[k]), p);      // (the queue still holds the density samples)
             normalize(F, p, u);
             const size_t e = (size_t)eb + k;
             io.ent_xyz[e * 3] = u[0];
@@ -209,7 +232,7 @@ __global__ __launch_bounds__(64) void march_forward_kernel(const TfField F, cons
     }
     base = __shfl(base, 0, 64);
     for (int j = lane; j < appcnt; j += 64) {
-        const int idx = q[j];
+        const int idx = qs[j];
         float p[3], u[3];
         sample_pos(ray, sample_z(F, ray, ztab, idx), p);
         normalize(F, p, u);
@@ -220,6 +243,8 @@ __global__ __launch_bounds__(64) void march_forward_kernel(const TfField F, cons
         io.app_xyz[s * 3 + 2] = u[2];
         io.app_w[s] = wq[j];
     }
+    TF_MARK(3);
+    TF_FLUSH();
 }
 
 // compute_densityfeature on an explicit list of normalised points (the public hook used by compute_alpha,
@@ -396,6 +421,18 @@ __global__ __launch_bounds__(256) void composite_kernel(int n_rays, const int* _
 
 extern "C" {
 
+#ifdef TF_PHASE_TIMING
+int tf_debug_phase_cycles_march(unsigned long long* out16, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(tf_phase_cycles), sizeof(unsigned long long) * 16);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(tf_phase_cycles), z, sizeof(z));
+    }
+    return (int)e;
+}
+#endif
+
+
 int tf_pack_alpha_cells(const float* volume, int gx, int gy, int gz, uint8_t* cells, tf_stream_t stream) {
     const size_t total = (size_t)(gx + 1) * (gy + 1) * (gz + 1);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
@@ -443,7 +480,9 @@ int tf_march_forward(const TfField* field, const TfMarchIO* io, tf_stream_t stre
     if (io->n_rays <= 0) return 0;
     if (io->n_samples <= 0 || io->n_samples > TF_MAX_SAMPLES) return (int)hipErrorInvalidValue;
     const int ncap = (io->n_samples + 63) & ~63;
-    const size_t lds = (size_t)ncap * 6 + 256;
+    const size_t lds = (size_t)ncap * 8 + 256;      // weights (4 B), density queue and shaded queue (2 B each), 64 features
+    const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(march_forward_kernel), lds);   // (> 64 KB at N = 8192)
+    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(march_forward_kernel, dim3(io->n_rays), dim3(64), lds, (hipStream_t)stream, *field, *io);
     return TF_CHECK_LAUNCH();
 }

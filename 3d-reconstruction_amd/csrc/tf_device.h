@@ -186,6 +186,30 @@ __device__ __forceinline__ void normalize(const TfField& F, const float p[3], fl
 // grid_sample unnormalize, align_corners=True
 __device__ __forceinline__ float unnorm(float u, int size) { return ((u + 1.f) * 0.5f) * (float)(size - 1); }
 
+// alpha_hit in two steps, so that a caller can have several cell loads in flight: the cell's index and the corner bits that
+// count for this point (false: every corner out of bounds — no hit, nothing to load) ...
+__device__ __forceinline__ bool alpha_cell(const TfField& F, const float p[3], size_t& cell, uint32_t& allow) {
+    float f[3];
+    int c[3];
+    bool in = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float t = p[a] - F.alpha_lo[a];
+        float s = t * F.alpha_inv[a];
+        float u = s - 1.f;
+        float x = unnorm(u, F.alpha_grid[a]);
+        in &= (x > -1.f) & (x < (float)F.alpha_grid[a]);      // (NaN: out)
+        float x0 = floorf(x);
+        f[a] = x - x0;
+        c[a] = (int)x0 + 1;  // 0 .. G
+    }
+    const int sx = F.alpha_grid[0] + 1, sy = F.alpha_grid[1] + 1;
+    cell = in ? ((size_t)c[2] * sy + c[1]) * sx + c[0] : 0;
+    allow = (f[0] > 0.f ? 0xFFu : 0x55u) & (f[1] > 0.f ? 0xFFu : 0x33u) & (f[2] > 0.f ? 0xFFu : 0x0Fu);
+    return in;
+}
+// ... and the test of the loaded byte: (F.alpha_cells[cell] & allow) != 0
+
 // AlphaGridMask.sample_alpha(p) > 0   (tensorBase.py:41-48, 350-351) through the 1-byte cell table.
 __device__ __forceinline__ bool alpha_hit(const TfField& F, const float p[3]) {
     float f[3];
