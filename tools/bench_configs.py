@@ -17,7 +17,7 @@ for name in sys.argv[1:] or ["C1_vm128", "C2_vm300", "C3_cp300_sh", "C3_cp300_ml
     def ev():
         with torch.no_grad():
             model(rays, None, white_bg=white, is_train=False, ndc_ray=ndc, N_samples=N)
-    for _ in range(5): ev()
+    for _ in range(25): ev()      # (also grows the allocator's pools: the first calls after a model switch stall in hipMalloc)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(30): ev()
     torch.cuda.synchronize(); t_eval = (time.perf_counter() - t0) / 30
