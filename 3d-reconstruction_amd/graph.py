@@ -170,6 +170,10 @@ class GraphedTrainStep:
             add_regularizer_grads_(self.model, 1.0, 1.0, 1.0, 1.0, weights_dev=self._regw)
         # (the buffer was handed out by this step's backward: not clean, and p.grad are views of it)
         consume = self._store() is not None and self._gstore['flat'] is not None and not self._gstore['clean']
+        if consume:      # ... provided autograd kept the views it was handed (a cloned gradient would leave the buffer dirty:
+            flat = self._gstore['flat']      # then it is simply zero-filled at the next hand-out)
+            g = next((p.grad for p in self.model.parameters() if p.grad is not None), None)
+            consume = g is not None and flat.data_ptr() <= g.data_ptr() < flat.data_ptr() + 4 * flat.numel()
         if not consume:
             self.opt.step()
             return

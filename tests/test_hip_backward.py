@@ -211,6 +211,12 @@ def test_graphed_fused_adam_follows_lr_schedule(recon):
             for grp in opt.param_groups:
                 grp['lr'] = grp['lr'] * 0.7
         assert not graphed or gs.graph is not None
+        if graphed:     # the captured step accumulates into ONE gradient buffer that FusedAdam returns to zero
+            flat = gs._gstore['flat']
+            assert flat is not None and gs._gstore['clean'] and int(torch.count_nonzero(flat)) == 0
+            assert all(p.grad is not None and flat.data_ptr() <= p.grad.data_ptr() < flat.data_ptr() + 4 * flat.numel()
+                       for p in model.parameters())
+            assert opt.consume_grads is False          # the optimizer's own setting is restored after every step
         finals.append({k: v.detach().clone() for k, v in model.state_dict().items()})
     _same_trajectory(finals, init, losses)
 
