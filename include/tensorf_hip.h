@@ -248,8 +248,9 @@ int tf_march_backward(const TfField* field, const TfMarchIO* io, const float* gr
 
 /* Backward of the shading head + appearance lookup (autograd of tensoRF.py:230-263, mlp.py:27-155) on the rows the
  * training forward saved (TfShadeSave: MLP inputs, both hidden layers and the plane*line products; the colours are
- * the forward's rgb_out) — nothing of the forward is recomputed: accumulates gradients of w1,b1,w2,b2,w3,b3, basis
- * and the appearance factors.  Gradient matrices use the reference's own (unpadded, row-major) layouts. */
+ * the forward's rgb_out) — nothing of the forward is recomputed.  The gradients of b1, b2, w3, b3 and of the appearance
+ * factors are ADDED to what the buffers hold (zero them first); those of w1, w2 and basis are WRITTEN (the fold of the
+ * workgroups' slabs, wslab).  Gradient matrices use the reference's own (unpadded, row-major) layouts. */
 typedef struct TfShadeGrads {
     float* w1; float* b1; float* w2; float* b2; float* w3; float* b3;
     float* basis;          /* (app_dim, n_app_total) */
