@@ -203,9 +203,14 @@ __global__ __launch_bounds__(64) void filter_rays_kernel(const TfField F, const 
 // allrays[ray_idx], allrgbs[ray_idx] (train.py:297-298) in one launch: thread t moves float t of the 9 the batch row has
 __global__ __launch_bounds__(256) void gather_batch_kernel(const float* __restrict__ rays, const float* __restrict__ rgbs,
                                                            const long long* __restrict__ ids, long long n_all, int n,
-                                                           float* __restrict__ rays_out, float* __restrict__ rgbs_out) {
+                                                           float* __restrict__ rays_out, float* __restrict__ rgbs_out,
+                                                           const float* __restrict__ extra_src, float* __restrict__ extra_dst,
+                                                           int n_extra) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * 9) return;
+    if (t >= n * 9) {      // the tail of the grid moves the step's host-drawn numbers (pinned host memory, read in place)
+        if (t - n * 9 < n_extra) extra_dst[t - n * 9] = extra_src[t - n * 9];
+        return;
+    }
     const int row = t / 9, c = t - row * 9;
     long long src = ids[row];
     if (src < 0) src += n_all;                       // torch indexing semantics for negative ids
@@ -268,12 +273,19 @@ __global__ __launch_bounds__(256) void generate_rays_kernel(const TfCamera cam, 
 
 extern "C" {
 
+int tf_gather_batch_staged(const float* rays, const float* rgbs, long long n_all, const long long* ids, int n, float* rays_out,
+                           float* rgbs_out, const float* extra_src, float* extra_dst, int n_extra, tf_stream_t stream) {
+    if (n <= 0 && n_extra <= 0) return 0;
+    if (n < 0 || n_extra < 0 || (n_extra > 0 && (!extra_src || !extra_dst))) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(gather_batch_kernel, dim3((n * 9 + n_extra + 255) / 256), dim3(256), 0, (hipStream_t)stream, rays, rgbs, ids,
+                       n_all, n, rays_out, rgbs_out, extra_src, extra_dst, n_extra);
+    return TF_CHECK_LAUNCH();
+}
+
 int tf_gather_batch(const float* rays, const float* rgbs, long long n_all, const long long* ids, int n, float* rays_out,
                     float* rgbs_out, tf_stream_t stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(gather_batch_kernel, dim3((n * 9 + 255) / 256), dim3(256), 0, (hipStream_t)stream, rays, rgbs, ids, n_all, n,
-                       rays_out, rgbs_out);
-    return TF_CHECK_LAUNCH();
+    return tf_gather_batch_staged(rays, rgbs, n_all, ids, n, rays_out, rgbs_out, nullptr, nullptr, 0, stream);
 }
 
 int tf_generate_rays(const TfCamera* cam, const long long* pixel_ids, long long first_pixel, int n, float* rays_out,

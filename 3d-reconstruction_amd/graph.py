@@ -60,6 +60,7 @@ class GraphedTrainStep:
         # the step's gradient buffer, kept across steps when the optimizer is a FusedAdam: its launch returns every gradient
         # it consumed to zero (consume_grads), so the backward accumulates into the same buffer again without a fill
         self._gstore = {'flat': None, 'clean': True}
+        self._jit_ring, self._jit_i = None, 0              # pinned jitter buffers of _stage (ring)
         self.n_samples, self.mask, self.ndc = n_samples, mask, ndc_ray
         # white_bg=False (datasets without a white background, e.g. llff.py:141): the reference adds the white
         # background to a training batch with probability 1/2 (tensorBase.py:380) — a host decision per step, so the
@@ -204,9 +205,24 @@ class GraphedTrainStep:
               and target.dtype == torch.float32 and rays.is_contiguous() and target.is_contiguous()
               and rays.shape[1:] == (6,) and target.shape[1:] == (3,) and target.shape[0] == rays.shape[0]
               and ids.numel() == self.rays.shape[0]):
-            # allrays[ray_idx], allrgbs[ray_idx] (train.py:297-298) straight into the static buffers, one launch
-            H.check(H.lib().tf_gather_batch(rays.data_ptr(), target.data_ptr(), rays.shape[0], ids.contiguous().data_ptr(), ids.numel(),
-                                            self.rays.data_ptr(), self.target.data_ptr(), _stream()), "tf_gather_batch")
+            # allrays[ray_idx], allrgbs[ray_idx] (train.py:297-298) straight into the static buffers, one launch — which also
+            # reads the step's jitter draw out of pinned host memory (no upload launch of its own).  The pinned buffers go
+            # round a ring: a slot is rewritten only after the launch that read it has run (the host issues replays far ahead)
+            R = self.rays.shape[0]
+            if self._jit_ring is None:
+                self._jit_ring = [[torch.empty(R, 1).pin_memory(), None] for _ in range(32)]
+            slot = self._jit_ring[self._jit_i % len(self._jit_ring)]
+            self._jit_i += 1
+            if slot[1] is not None:
+                slot[1].synchronize()
+            torch.rand(R, 1, out=slot[0])                      # same CPU-generator draw as the reference
+            H.check(H.lib().tf_gather_batch_staged(rays.data_ptr(), target.data_ptr(), rays.shape[0], ids.contiguous().data_ptr(),
+                                                   ids.numel(), self.rays.data_ptr(), self.target.data_ptr(), slot[0].data_ptr(),
+                                                   self.jitter.data_ptr(), R, _stream()), "tf_gather_batch_staged")
+            if slot[1] is None:
+                slot[1] = torch.cuda.Event()
+            slot[1].record()
+            return
         else:
             torch.index_select(rays, 0, ids, out=self.rays)
             torch.index_select(target, 0, ids, out=self.target)

@@ -196,6 +196,15 @@ def test_batch_gather_matches_indexing(recon):
     H.check(H.lib().tf_gather_batch(rays.data_ptr(), rgbs.data_ptr(), 10007, ids.data_ptr(), 4096, out_r.data_ptr(),
                                     out_c.data_ptr(), torch.cuda.current_stream().cuda_stream), "tf_gather_batch")
     assert torch.equal(out_r, rays[ids]) and torch.equal(out_c, rgbs[ids])
+    # the staged form: the same gather, and the step's host-drawn jitter read out of pinned host memory by the same launch
+    jit = torch.rand(4096, 1, generator=g).pin_memory()
+    out_r.zero_(); out_c.zero_()
+    out_j = torch.zeros(4096, device=DEV)
+    H.check(H.lib().tf_gather_batch_staged(rays.data_ptr(), rgbs.data_ptr(), 10007, ids.data_ptr(), 4096, out_r.data_ptr(),
+                                           out_c.data_ptr(), jit.data_ptr(), out_j.data_ptr(), 4096,
+                                           torch.cuda.current_stream().cuda_stream), "tf_gather_batch_staged")
+    torch.cuda.synchronize()
+    assert torch.equal(out_r, rays[ids]) and torch.equal(out_c, rgbs[ids]) and torch.equal(out_j.cpu(), jit.view(-1))
 
 
 @pytest.mark.parametrize("n_rays", [1, 3, 9, 70])
