@@ -138,7 +138,7 @@ _SIGS = {
     "tf_pack_matrix_t": [_fp, C.c_int, C.c_int, _fp, C.c_int, _fp],
     "tf_pack_matrices": [C.POINTER(TfPackJob), _fp],
     "tf_gather_batch": [_fp, _fp, C.c_longlong, _fp, C.c_int, _fp, _fp, _fp],
-    "tf_gather_batch_staged": [_fp, _fp, C.c_longlong, _fp, C.c_int, _fp, _fp, _fp, _fp, C.c_int, _fp],
+    "tf_gather_batch_staged": [_fp, _fp, C.c_longlong, _fp, C.c_int, _fp, _fp, _fp, _fp, C.c_int, C.POINTER(TfPackJob), _fp],
     "tf_gather_rows": [_fp, _fp, C.c_int, C.c_int, _fp, _fp],
     "tf_scatter_rows": [_fp, _fp, C.c_int, C.c_int, _fp, _fp],
     "tf_mse_grad": [_fp, _fp, C.c_int, C.c_float, _fp, _fp, _fp],

@@ -205,7 +205,12 @@ __global__ __launch_bounds__(256) void gather_batch_kernel(const float* __restri
                                                            const long long* __restrict__ ids, long long n_all, int n,
                                                            float* __restrict__ rays_out, float* __restrict__ rgbs_out,
                                                            const float* __restrict__ extra_src, float* __restrict__ extra_dst,
-                                                           int n_extra) {
+                                                           int n_extra, int n_gather_wgs, int pack_gx, const TfPackJob pack) {
+    if ((int)blockIdx.x >= n_gather_wgs) {      // the workgroups behind the gather run the step's weight-pack job
+        const int pb = (int)blockIdx.x - n_gather_wgs;
+        tf::pack_block(pack, pb % pack_gx, pb / pack_gx, pack_gx);
+        return;
+    }
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * 9) {      // the tail of the grid moves the step's host-drawn numbers (pinned host memory, read in place)
         if (t - n * 9 < n_extra) extra_dst[t - n * 9] = extra_src[t - n * 9];
@@ -274,18 +279,24 @@ __global__ __launch_bounds__(256) void generate_rays_kernel(const TfCamera cam, 
 extern "C" {
 
 int tf_gather_batch_staged(const float* rays, const float* rgbs, long long n_all, const long long* ids, int n, float* rays_out,
-                           float* rgbs_out, const float* extra_src, float* extra_dst, int n_extra, tf_stream_t stream) {
-    if (n <= 0 && n_extra <= 0) return 0;
+                           float* rgbs_out, const float* extra_src, float* extra_dst, int n_extra, const TfPackJob* pack,
+                           tf_stream_t stream) {
     if (n < 0 || n_extra < 0 || (n_extra > 0 && (!extra_src || !extra_dst))) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(gather_batch_kernel, dim3((n * 9 + n_extra + 255) / 256), dim3(256), 0, (hipStream_t)stream, rays, rgbs, ids,
-                       n_all, n, rays_out, rgbs_out, extra_src, extra_dst, n_extra);
+    if (pack && (pack->n < 1 || pack->n > TF_PACK_MAX)) return (int)hipErrorInvalidValue;
+    const int gather_wgs = (n * 9 + n_extra + 255) / 256;
+    TfPackJob none{};
+    const TfPackJob& pj = pack ? *pack : none;
+    const int gx = pack ? tf::pack_grid_x(pj) : 1, gy = pack ? pj.n + ((pj.n_zero > 0 && pj.zero) ? 1 : 0) : 0;
+    if (gather_wgs + gx * gy <= 0) return 0;
+    hipLaunchKernelGGL(gather_batch_kernel, dim3(gather_wgs + gx * gy), dim3(256), 0, (hipStream_t)stream, rays, rgbs, ids,
+                       n_all, n, rays_out, rgbs_out, extra_src, extra_dst, n_extra, gather_wgs, gx, pj);
     return TF_CHECK_LAUNCH();
 }
 
 int tf_gather_batch(const float* rays, const float* rgbs, long long n_all, const long long* ids, int n, float* rays_out,
                     float* rgbs_out, tf_stream_t stream) {
     if (n <= 0) return 0;
-    return tf_gather_batch_staged(rays, rgbs, n_all, ids, n, rays_out, rgbs_out, nullptr, nullptr, 0, stream);
+    return tf_gather_batch_staged(rays, rgbs, n_all, ids, n, rays_out, rgbs_out, nullptr, nullptr, 0, nullptr, stream);
 }
 
 int tf_generate_rays(const TfCamera* cam, const long long* pixel_ids, long long first_pixel, int n, float* rays_out,

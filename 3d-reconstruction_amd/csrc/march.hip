@@ -307,23 +307,7 @@ __global__ __launch_bounds__(256) void pack_matrix_t_kernel(const float* __restr
 // several pack jobs in one launch (blockIdx.y = job): the training step refreshes 5 padded / transposed weight
 // copies after every optimizer step
 __global__ __launch_bounds__(256) void pack_matrices_kernel(const TfPackJob J) {
-    if ((int)blockIdx.y == J.n) {      // extra row of workgroups: the forward's zero block rides along
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < J.n_zero; i += gridDim.x * blockDim.x) J.zero[i] = 0;
-        return;
-    }
-    const TfPackItem& P = J.item[blockIdx.y];
-    const int kp = (P.cols + 15) & ~15, total = P.rows_pad * kp;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        int r, c;
-        if (P.transpose) {
-            c = i / P.rows_pad;
-            r = i - c * P.rows_pad;
-        } else {
-            r = i / kp;
-            c = i - r * kp;
-        }
-        P.dst[i] = (r < P.rows && c < P.cols) ? P.src[(size_t)r * P.cols + c] : 0.f;
-    }
+    pack_block(J, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
 }
 
 // loss = mean((a - b)^2) over n floats and grad = d loss / d a = 2 (a - b) / n, one workgroup (n is 3 x rays)
@@ -459,13 +443,8 @@ int tf_pack_matrix_t(const float* src, int rows, int cols, float* dst, int rows_
 
 int tf_pack_matrices(const TfPackJob* job, tf_stream_t stream) {
     if (job->n < 1 || job->n > TF_PACK_MAX) return (int)hipErrorInvalidValue;
-    int most = 0;
-    for (int k = 0; k < job->n; ++k) {
-        const int total = job->item[k].rows_pad * ((job->item[k].cols + 15) & ~15);
-        most = total > most ? total : most;
-    }
     const bool zero = job->n_zero > 0 && job->zero;
-    hipLaunchKernelGGL(pack_matrices_kernel, dim3((most + 255) / 256, job->n + (zero ? 1 : 0)), dim3(256), 0,
+    hipLaunchKernelGGL(pack_matrices_kernel, dim3(pack_grid_x(*job), job->n + (zero ? 1 : 0)), dim3(256), 0,
                        (hipStream_t)stream, *job);
     return TF_CHECK_LAUNCH();
 }

@@ -63,6 +63,37 @@ static __device__ unsigned long long tf_phase_cycles_w4[16];      // the same, s
 
 typedef float float4_t __attribute__((ext_vector_type(4)));
 
+// One workgroup's share of a TfPackJob: row `by` of a (gx, n + 1) grid of 256-thread workgroups — rows 0 .. n-1 write the
+// padded (or transposed) weight copies, row n zeroes the job's counter / histogram block.  Shared by tf_pack_matrices and
+// the staging launch of the captured training step (tf_gather_batch_staged).
+__device__ __forceinline__ void pack_block(const TfPackJob& J, int bx, int by, int gx) {
+    if (by == J.n) {
+        for (int i = bx * 256 + (int)threadIdx.x; i < J.n_zero; i += gx * 256) J.zero[i] = 0;
+        return;
+    }
+    const TfPackItem& P = J.item[by];
+    const int kp = (P.cols + 15) & ~15, total = P.rows_pad * kp;
+    for (int i = bx * 256 + (int)threadIdx.x; i < total; i += gx * 256) {
+        int r, c;
+        if (P.transpose) {
+            c = i / P.rows_pad;
+            r = i - c * P.rows_pad;
+        } else {
+            r = i / kp;
+            c = i - r * kp;
+        }
+        P.dst[i] = (r < P.rows && c < P.cols) ? P.src[(size_t)r * P.cols + c] : 0.f;
+    }
+}
+__host__ inline int pack_grid_x(const TfPackJob& J) {      // workgroups per row: the largest item sets it
+    int most = 0;
+    for (int k = 0; k < J.n; ++k) {
+        const int total = J.item[k].rows_pad * ((J.item[k].cols + 15) & ~15);
+        most = total > most ? total : most;
+    }
+    return (most + 255) / 256;
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains this wave's outstanding GLOBAL
 // loads and stores (s_waitcnt vmcnt(0)), which stalls kernels that keep global stores (or prefetches of the next
 // operands) in flight across phase boundaries.  Use only where the data exchanged between waves lives in LDS.

@@ -269,6 +269,7 @@ class TensorBase(nn.Module):
         self.early_sort = False
         self._sort_stream = None
         self._bin_status = None
+        self._pack_external = None   # graph.GraphedTrainStep, while capturing: {'job': the forward's TfPackJob} instead of a launch
         self._grad_store = None      # graph.GraphedTrainStep: the gradient buffer its steps share (autograd._grad_buffers)
         # tf_shade_forward workgroups (of 512 CU slots) while the early sorts run next to it; the sort kernels need a CU
         # slot's LDS and registers (measured at config 2 with the 16-sample work split: 384 / 448 / 480 / 496 / 504 / 512 workgroups ->
@@ -525,7 +526,13 @@ class TensorBase(nn.Module):
             zero.zero_()
             return
         job.zero, job.n_zero = zero.data_ptr(), zero.numel()
-        H.check(H.lib().tf_pack_matrices(C.byref(job), _stream()), "tf_pack_matrices")
+        ext = self._pack_external
+        if ext is not None:      # graph.GraphedTrainStep is capturing: it runs this job itself, in front of every replay
+            # (riding on its batch-staging launch), so the graph holds no pack launch.  A COPY: the plan's struct is shared by
+            # every forward of this model, and each captured variant has its own workspace (zero block)
+            ext['job'] = H.TfPackJob.from_buffer_copy(job)
+        else:
+            H.check(H.lib().tf_pack_matrices(C.byref(job), _stream()), "tf_pack_matrices")
         for w in watch:
             w[1] = w[0]._version
         self._pack_tags_from(watch)               # keep the generic cache's tags truthful

@@ -61,6 +61,7 @@ class GraphedTrainStep:
         # it consumed to zero (consume_grads), so the backward accumulates into the same buffer again without a fill
         self._gstore = {'flat': None, 'clean': True}
         self._jit_ring, self._jit_i = None, 0              # pinned jitter buffers of _stage (ring)
+        self._packjobs = {}                                # use_bg -> the captured forward's TfPackJob (run by _stage)
         self.n_samples, self.mask, self.ndc = n_samples, mask, ndc_ray
         # white_bg=False (datasets without a white background, e.g. llff.py:141): the reference adds the white
         # background to a training batch with probability 1/2 (tensorBase.py:380) — a host decision per step, so the
@@ -197,43 +198,61 @@ class GraphedTrainStep:
             self._fwd_bwd()
         self._regs_and_opt()
 
-    def _stage(self, rays, target, ids=None):
-        if ids is None:
-            self.rays.copy_(rays, non_blocking=True)
-            self.target.copy_(target, non_blocking=True)
-        elif (rays.is_cuda and target.is_cuda and ids.is_cuda and ids.dtype == torch.int64 and rays.dtype == torch.float32
-              and target.dtype == torch.float32 and rays.is_contiguous() and target.is_contiguous()
-              and rays.shape[1:] == (6,) and target.shape[1:] == (3,) and target.shape[0] == rays.shape[0]
-              and ids.numel() == self.rays.shape[0]):
-            # allrays[ray_idx], allrgbs[ray_idx] (train.py:297-298) straight into the static buffers, one launch — which also
-            # reads the step's jitter draw out of pinned host memory (no upload launch of its own).  The pinned buffers go
-            # round a ring: a slot is rewritten only after the launch that read it has run (the host issues replays far ahead)
-            R = self.rays.shape[0]
-            if self._jit_ring is None:
-                self._jit_ring = [[torch.empty(R, 1).pin_memory(), None] for _ in range(32)]
-            slot = self._jit_ring[self._jit_i % len(self._jit_ring)]
-            self._jit_i += 1
-            if slot[1] is not None:
-                slot[1].synchronize()
-            torch.rand(R, 1, out=slot[0])                      # same CPU-generator draw as the reference
+    def _draw_jitter(self):
+        """The step's sampling jitter, drawn from the CPU generator like the reference does (tensorBase.py:198-203), into a
+        pinned buffer the staging launch reads in place.  The buffers go round a ring: a slot is rewritten only after the
+        launch that read it has run (the host issues replays far ahead of the GPU)."""
+        R = self.rays.shape[0]
+        if self._jit_ring is None:
+            self._jit_ring = [[torch.empty(R, 1).pin_memory(), None] for _ in range(32)]
+        slot = self._jit_ring[self._jit_i % len(self._jit_ring)]
+        self._jit_i += 1
+        if slot[1] is not None:
+            slot[1].synchronize()
+        torch.rand(R, 1, out=slot[0])
+        return slot
+
+    def _stage(self, rays, target, ids, slot):
+        """Batch, jitter and — once the step is captured — the forward's weight-pack job, in one launch where possible."""
+        job = self._packjobs.get(self._bg) if self._graphs.get(self._bg) is not None else None
+        R = self.rays.shape[0]
+        if (ids is not None and rays.is_cuda and target.is_cuda and ids.is_cuda and ids.dtype == torch.int64
+                and rays.dtype == torch.float32 and target.dtype == torch.float32 and rays.is_contiguous()
+                and target.is_contiguous() and rays.shape[1:] == (6,) and target.shape[1:] == (3,)
+                and target.shape[0] == rays.shape[0] and ids.numel() == R):
+            # allrays[ray_idx], allrgbs[ray_idx] (train.py:297-298) straight into the static buffers
             H.check(H.lib().tf_gather_batch_staged(rays.data_ptr(), target.data_ptr(), rays.shape[0], ids.contiguous().data_ptr(),
-                                                   ids.numel(), self.rays.data_ptr(), self.target.data_ptr(), slot[0].data_ptr(),
-                                                   self.jitter.data_ptr(), R, _stream()), "tf_gather_batch_staged")
-            if slot[1] is None:
-                slot[1] = torch.cuda.Event()
-            slot[1].record()
-            return
+                                                   R, self.rays.data_ptr(), self.target.data_ptr(), slot[0].data_ptr(),
+                                                   self.jitter.data_ptr(), R, C.byref(job) if job is not None else None,
+                                                   _stream()), "tf_gather_batch_staged")
         else:
-            torch.index_select(rays, 0, ids, out=self.rays)
-            torch.index_select(target, 0, ids, out=self.target)
-        j = torch.rand(self.rays.shape[0], 1, pin_memory=True)   # same CPU-generator draw as the reference
-        self.jitter.copy_(j.view(-1), non_blocking=True)
+            if ids is None:
+                self.rays.copy_(rays, non_blocking=True)
+                self.target.copy_(target, non_blocking=True)
+            else:
+                torch.index_select(rays, 0, ids, out=self.rays)
+                torch.index_select(target, 0, ids, out=self.target)
+            H.check(H.lib().tf_gather_batch_staged(None, None, 0, None, 0, None, None, slot[0].data_ptr(), self.jitter.data_ptr(),
+                                                   R, C.byref(job) if job is not None else None, _stream()),
+                    "tf_gather_batch_staged")
+        if slot[1] is None:
+            slot[1] = torch.cuda.Event()
+        slot[1].record()
 
     def step(self, rays, target, ids=None):
         """One optimisation step on (rays, target) — or on rows `ids` of them; returns the (device) loss tensor."""
-        self._stage(rays, target, ids)
+        if self._graphs and not self._same(self._signature(), self._captured_for):
+            # the model changed under the graph (updateAlphaMask / shrink / upsample_volume_grid replace the mask and the
+            # parameters, train.py:300-311): the captured pointers are stale -> warm up and capture again.  (Checked before
+            # the staging launch, which runs the captured forward's weight-pack job.)
+            self._graphs = {}
+            self._packjobs = {}
+            self.graph = self.graph_opt = None
+            self._warm = 1
+        slot = self._draw_jitter()
         # random-background draw of tensorBase.py:380, taken after the jitter draw like the reference's forward does
         self._bg = True if self.white_bg else bool(torch.rand((1,)) < 0.5)
+        self._stage(rays, target, ids, slot)
         self.model._bg_override = self._bg
         try:
             return self._step()
@@ -243,12 +262,6 @@ class GraphedTrainStep:
     def _step(self):
         if hasattr(self.opt, "sync_lr") and self.opt._lr_dev is not None:
             self.opt.sync_lr()                                    # FusedAdam: lr schedule follows the host values
-        if self._graphs and not self._same(self._signature(), self._captured_for):
-            # the model changed under the graph (updateAlphaMask / shrink / upsample_volume_grid replace the mask and the
-            # parameters, train.py:300-311): the captured pointers are stale -> warm up and capture again
-            self._graphs = {}
-            self.graph = self.graph_opt = None
-            self._warm = 1
         hit = self._graphs.get(self._bg)
         if hit is not None:
             if not self.split:
@@ -281,11 +294,20 @@ class GraphedTrainStep:
         self._captured_for = self._signature()
         pool = next(iter(self._graphs.values()))[0].pool() if self._graphs else None     # one pool for all variants
         g = torch.cuda.CUDAGraph()
+        ext = self.model._pack_external = {}     # the forward hands its weight-pack job over instead of launching it
+        try:
+            if not self.split:
+                with torch.cuda.graph(g, stream=self._side, pool=pool):
+                    self._body()
+        except BaseException:
+            self.model._pack_external = None
+            raise
         if not self.split:
-            with torch.cuda.graph(g, stream=self._side, pool=pool):
-                self._body()
+            self.model._pack_external = None
+            self._packjobs[self._bg] = ext.get('job')
             self._graphs[self._bg] = (g, None)
             self.graph = g
+            self._run_pack_job()                                  # (this step was staged before its graph existed)
             g.replay()                                            # capture only records; run this step now
             self._after_replay()
             return self.loss
@@ -294,8 +316,12 @@ class GraphedTrainStep:
         # between, the density bucket travelling while (b) replays.  Thread-local capture mode: the process group's
         # helper threads (RCCL proxy / watchdog, gloo workers) may make HIP calls of their own while this thread
         # captures; they never touch the captured stream.
-        with torch.cuda.graph(g, stream=self._side, pool=pool, capture_error_mode="thread_local"):
-            self._fwd_density()
+        try:
+            with torch.cuda.graph(g, stream=self._side, pool=pool, capture_error_mode="thread_local"):
+                self._fwd_density()
+        finally:
+            self.model._pack_external = None
+        self._packjobs[self._bg] = ext.get('job')
         gb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gb, stream=self._side, pool=g.pool(), capture_error_mode="thread_local"):
             self._shade_half()
@@ -304,9 +330,15 @@ class GraphedTrainStep:
             self._regs_and_opt()
         self._graphs[self._bg] = (g, g2, gb)
         self.graph, self.graph_opt = g, g2
+        self._run_pack_job()
         self._replay_split(self._graphs[self._bg])
         self._after_replay()
         return self.loss
+
+    def _run_pack_job(self):
+        job = self._packjobs.get(self._bg)
+        if job is not None:
+            H.check(H.lib().tf_pack_matrices(C.byref(job), _stream()), "tf_pack_matrices")
 
     def _replay_split(self, graphs):
         ga, gopt, gb = graphs

@@ -319,9 +319,12 @@ int tf_gather_batch(const float* rays, const float* rgbs, long long n_all, const
                     float* rgbs_out, tf_stream_t stream);
 /* The same launch also moving n_extra floats extra_src -> extra_dst: the step's host-drawn numbers (the per-ray sampling
  * jitter of tensorBase.py:198-203, drawn from the CPU generator like the reference does).  extra_src may be pinned host
- * memory (read in place by the kernel: no copy launch of its own); the caller keeps it alive until the launch has run. */
+ * memory (read in place by the kernel: no copy launch of its own); the caller keeps it alive until the launch has run.
+ * `pack` (optional): a tf_pack_matrices job run by extra workgroups of the same launch — the captured training step's
+ * weight copies and zeroed counter block, which then need no launch inside the graph. */
 int tf_gather_batch_staged(const float* rays, const float* rgbs, long long n_all, const long long* ids, int n, float* rays_out,
-                           float* rgbs_out, const float* extra_src, float* extra_dst, int n_extra, tf_stream_t stream);
+                           float* rgbs_out, const float* extra_src, float* extra_dst, int n_extra, const TfPackJob* pack,
+                           tf_stream_t stream);
 int tf_generate_rays(const TfCamera* cam, const long long* pixel_ids, long long first_pixel, int n, float* rays_out,
                      tf_stream_t stream);
 

@@ -200,11 +200,28 @@ def test_batch_gather_matches_indexing(recon):
     jit = torch.rand(4096, 1, generator=g).pin_memory()
     out_r.zero_(); out_c.zero_()
     out_j = torch.zeros(4096, device=DEV)
+    # ... and a weight-pack job (padded copy, padded transpose, zeroed counter block) run by extra workgroups of that launch
+    w = torch.randn(37, 21, generator=g).to(DEV)
+    dst, dst_t = torch.full((48, 32), 7.0, device=DEV), torch.full((32, 48), 7.0, device=DEV)
+    ctr = torch.full((1000,), 5, dtype=torch.int32, device=DEV)
+    job = H.TfPackJob()
+    job.n, job.zero, job.n_zero = 2, ctr.data_ptr(), ctr.numel()
+    for it, (d, tr) in zip(job.item, ((dst, 0), (dst_t, 1))):
+        it.src, it.dst, it.rows, it.cols, it.rows_pad, it.transpose = w.data_ptr(), d.data_ptr(), 37, 21, 48, tr
     H.check(H.lib().tf_gather_batch_staged(rays.data_ptr(), rgbs.data_ptr(), 10007, ids.data_ptr(), 4096, out_r.data_ptr(),
-                                           out_c.data_ptr(), jit.data_ptr(), out_j.data_ptr(), 4096,
+                                           out_c.data_ptr(), jit.data_ptr(), out_j.data_ptr(), 4096, C.byref(job),
                                            torch.cuda.current_stream().cuda_stream), "tf_gather_batch_staged")
     torch.cuda.synchronize()
     assert torch.equal(out_r, rays[ids]) and torch.equal(out_c, rgbs[ids]) and torch.equal(out_j.cpu(), jit.view(-1))
+    want = torch.zeros(48, 32, device=DEV)
+    want[:37, :21] = w
+    assert torch.equal(dst, want) and torch.equal(dst_t, want.t()) and int(ctr.abs().sum()) == 0
+    # without a batch: jitter and pack job only (the staging of steps whose batch arrives by plain copies)
+    out_j.zero_(); dst.fill_(7.0)
+    H.check(H.lib().tf_gather_batch_staged(None, None, 0, None, 0, None, None, jit.data_ptr(), out_j.data_ptr(), 4096,
+                                           C.byref(job), torch.cuda.current_stream().cuda_stream), "tf_gather_batch_staged")
+    torch.cuda.synchronize()
+    assert torch.equal(out_j.cpu(), jit.view(-1)) and torch.equal(dst, want)
 
 
 @pytest.mark.parametrize("n_rays", [1, 3, 9, 70])
