@@ -10,8 +10,9 @@ stage the batch into the static input buffers, replay.
 
 Data parallel (`world_size > 1`): the step is captured as THREE graphs — (a) forward / loss / backward up to the density
 gradients, (b) shading backward + appearance scatter, (c) regularisers + optimizer — with the gradient exchange
-(`parallel.exchange_begin / exchange_end`, RCCL) issued eagerly in two buckets between the replays: the density bucket
-travels while (b) replays, so no collective is ever inside a capture and only the second bucket is exposed.
+(RCCL all-reduces of the two buckets' packed rows: `parallel.bucket_gather` closes graphs (a) and (b), `bucket_writeback`
+opens (c), only `bucket_reduce` runs eagerly between the replays): the density bucket travels while (b) replays, so no
+collective is ever inside a capture and only the second bucket is exposed.
 
 When the schedule replaces the alpha mask or the parameters (updateAlphaMask, shrink, upsample_volume_grid — the
 caller then assigns the rebuilt optimizer to `.opt`, as train.py:300-311 rebuilds it), the next `step` notices,
@@ -62,6 +63,8 @@ class GraphedTrainStep:
         self._gstore = {'flat': None, 'clean': True}
         self._jit_ring, self._jit_i = None, 0              # pinned jitter buffers of _stage (ring)
         self._packjobs = {}                                # use_bg -> the captured forward's TfPackJob (run by _stage)
+        self._dist = dist.is_available() and dist.is_initialized()
+        self._items, self._items_d, self._items_r = {}, [], []      # data parallel: the buckets' (buffer, rows, width) pieces
         self.n_samples, self.mask, self.ndc = n_samples, mask, ndc_ray
         # white_bg=False (datasets without a white background, e.g. llff.py:141): the reference adds the white
         # background to a training batch with probability 1/2 (tensorBase.py:380) — a host decision per step, so the
@@ -188,14 +191,29 @@ class GraphedTrainStep:
 
     def _body(self):
         if self.split:      # the eager warm-up runs the very sequence the three graphs will replay
-            self._fwd_density()
-            pend_d = parallel.exchange_begin(self.model, "density")
-            self._shade_half()
-            pend_r = parallel.exchange_begin(self.model, "rest")
-            parallel.exchange_end(self.model, pend_d, average=False)
-            parallel.exchange_end(self.model, pend_r, average=False)
+            self._part_a()
+            work_d = parallel.bucket_reduce(self._items_d)
+            self._part_b()
+            work_r = parallel.bucket_reduce(self._items_r)
+            for w in work_d + work_r:
+                w.wait()
+            self._part_c()
         else:
             self._fwd_bwd()
+            self._regs_and_opt()
+
+    # the three captured pieces of the data-parallel step: only the collectives themselves run between the replays — the
+    # packing of the rows that travel (tf_gather_rows) closes graphs (a) and (b), their write-back opens graph (c)
+    def _part_a(self):
+        self._fwd_density()
+        self._items_d = parallel.bucket_gather(self.model, "density") if self._dist else []
+
+    def _part_b(self):
+        self._shade_half()
+        self._items_r = parallel.bucket_gather(self.model, "rest") if self._dist else []
+
+    def _part_c(self):
+        parallel.bucket_writeback(self.model, self._items_d + self._items_r)    # (gradients are pre-divided by the world size)
         self._regs_and_opt()
 
     def _draw_jitter(self):
@@ -247,6 +265,7 @@ class GraphedTrainStep:
             # the staging launch, which runs the captured forward's weight-pack job.)
             self._graphs = {}
             self._packjobs = {}
+            self._items = {}
             self.graph = self.graph_opt = None
             self._warm = 1
         slot = self._draw_jitter()
@@ -318,16 +337,17 @@ class GraphedTrainStep:
         # captures; they never touch the captured stream.
         try:
             with torch.cuda.graph(g, stream=self._side, pool=pool, capture_error_mode="thread_local"):
-                self._fwd_density()
+                self._part_a()
         finally:
             self.model._pack_external = None
         self._packjobs[self._bg] = ext.get('job')
         gb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gb, stream=self._side, pool=g.pool(), capture_error_mode="thread_local"):
-            self._shade_half()
+            self._part_b()
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2, stream=self._side, pool=g.pool(), capture_error_mode="thread_local"):
-            self._regs_and_opt()
+            self._part_c()
+        self._items[self._bg] = (self._items_d, self._items_r)
         self._graphs[self._bg] = (g, g2, gb)
         self.graph, self.graph_opt = g, g2
         self._run_pack_job()
@@ -342,13 +362,13 @@ class GraphedTrainStep:
 
     def _replay_split(self, graphs):
         ga, gopt, gb = graphs
-        model = self.model
+        items_d, items_r = self._items[self._bg]
         ga.replay()
-        pend_d = parallel.exchange_begin(model, "density")      # on model.grad_flat: a static buffer of the graph's pool
+        work_d = parallel.bucket_reduce(items_d)                # on buffers of the graphs' pool: static addresses
         gb.replay()                                             # ... beside the density bucket's collective
-        pend_r = parallel.exchange_begin(model, "rest")
-        parallel.exchange_end(model, pend_d, average=False)     # (gradients are pre-divided by the world size)
-        parallel.exchange_end(model, pend_r, average=False)
+        work_r = parallel.bucket_reduce(items_r)
+        for w in work_d + work_r:
+            w.wait()                                            # (the compute stream waits, not the host, under RCCL)
         gopt.replay()
 
     def _after_replay(self):

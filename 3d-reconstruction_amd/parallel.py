@@ -270,16 +270,13 @@ def _bucket_rows(model):
     return res
 
 
-def exchange_begin(model, part, group=None):
-    """Starts the all-reduce (sum) of one bucket of model.grad_flat — part "density" or "rest" — and returns what
-    exchange_end needs.  With an alpha mask only the cells that can be non-zero travel (row gather -> all-reduce ->
-    row write-back, as in allreduce_gradients).  The collective is asynchronous: with RCCL it runs on the process
-    group's stream, ordered behind the kernels enqueued so far and beside those enqueued next."""
-    if not dist.is_available() or not dist.is_initialized():      # no process group: a one-process run, nothing travels
-        return []
+def bucket_gather(model, part):
+    """First third of a bucket's exchange, launches only (capturable in a hipGraph): the pieces of model.grad_flat that
+    travel for part "density" / "rest" — with an alpha mask the rows that can be non-zero, gathered into a packed buffer
+    (tf_gather_rows), else slices of the buffer itself.  Returns [(tensor to all-reduce, row index | None, row width)]."""
     flat = model.grad_flat
     br = _bucket_rows(model)
-    pending = []
+    items = []
     if br is not None and flat.is_cuda:
         from . import _hip as H
         from .field import _stream
@@ -289,30 +286,49 @@ def exchange_begin(model, part, group=None):
             buf = torch.empty(idx.numel(), w, dtype=torch.float32, device=flat.device)
             H.check(H.lib().tf_gather_rows(flat.data_ptr(), idx.data_ptr(), idx.numel(), w, buf.data_ptr(), _stream()),
                     "tf_gather_rows")
-            pending.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True), buf, idx, w))
+            items.append((buf, idx, w))
     else:
         dens, rest = _bucket_segments(model)
         for a, b in (dens if part == "density" else rest):
-            piece = flat[a:b]
-            pending.append((dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=group, async_op=True), piece, None, 0))
-    return pending
+            items.append((flat[a:b], None, 0))
+    return items
+
+
+def bucket_reduce(items, group=None):
+    """The collective itself (never inside a capture): one asynchronous all-reduce (sum) per piece; with RCCL it runs on
+    the process group's stream, ordered behind the kernels enqueued so far and beside those enqueued next."""
+    return [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t, _, _ in items]
+
+
+def bucket_writeback(model, items, scale=None):
+    """Last third, launches only (capturable): gathered rows go back into model.grad_flat (tf_scatter_rows)."""
+    flat = model.grad_flat
+    for buf, idx, w in items:
+        if scale is not None:
+            buf.mul_(scale)
+        if idx is not None:
+            from . import _hip as H
+            from .field import _stream
+            H.check(H.lib().tf_scatter_rows(flat.data_ptr(), idx.data_ptr(), idx.numel(), w, buf.data_ptr(), _stream()),
+                    "tf_scatter_rows")
+
+
+def exchange_begin(model, part, group=None):
+    """Starts the all-reduce (sum) of one bucket of model.grad_flat — part "density" or "rest" — and returns what
+    exchange_end needs (bucket_gather + bucket_reduce)."""
+    if not dist.is_available() or not dist.is_initialized():      # no process group: a one-process run, nothing travels
+        return []
+    items = bucket_gather(model, part)
+    return list(zip(bucket_reduce(items, group), items))
 
 
 def exchange_end(model, pending, average=True, group=None):
     """Waits for the bucket (the compute stream waits, not the host, under RCCL) and writes gathered rows back."""
     if not pending:
         return
-    world = dist.get_world_size(group)
-    flat = model.grad_flat
-    for work, buf, idx, w in pending:
+    for work, _ in pending:
         work.wait()
-        if average:
-            buf.mul_(1.0 / world)
-        if idx is not None:
-            from . import _hip as H
-            from .field import _stream
-            H.check(H.lib().tf_scatter_rows(flat.data_ptr(), idx.data_ptr(), idx.numel(), w, buf.data_ptr(), _stream()),
-                    "tf_scatter_rows")
+    bucket_writeback(model, [it for _, it in pending], 1.0 / dist.get_world_size(group) if average else None)
 
 
 def enable_overlapped_exchange(model, group=None):
