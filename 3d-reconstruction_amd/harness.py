@@ -176,6 +176,8 @@ def train(tensorf, allrays, allrgbs, cfg=None, device="cuda", rank=0, world=1, l
             hist["events"].append((it, "upsample", reso_cur, nSamples))
         hist["n_samples"].append(nSamples)
     gc.unfreeze()
+    if hasattr(tensorf, "check_scatter_status"):
+        tensorf.check_scatter_status()     # the binned scatter's sticky error word: nothing was refused during the run
     return hist
 
 

@@ -397,6 +397,8 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
+    if args.mode == "train":
+        model.check_scatter_status()     # raises if a scatter kernel of the timed steps refused an out-of-range position
     events = model.kernel_events
     model.kernel_events = None
     eager_ms = None
