@@ -224,11 +224,14 @@ __device__ __forceinline__ void dma_rows(const float* __restrict__ src, int wq, 
 // FT = feature_c/16 hidden feature tiles (4 or 8), NB = ceil(app_dim/16) (1..2), NTW = layer-1 k tiles per wave half
 // (2, 4, 5, 6 <-> up to 4, 8, 10, 12 k tiles).  WIDE: see BwdLds.  512 threads = 8 waves = 2 per SIMD.
 // Wave w: hidden feature tile ft = w % FT, sample group sg = w / FT (SG = 8/FT groups of NSW = 4/SG sample tiles).
-template <int FT, int NB, int NTW, bool WIDE>
+// MODE 0: V tile beside the rest, dV's basis operand staged in LDS (X region) | 1: WIDE | 2: as 0, basis from L2 (it does
+// not fit the X region: narrow MLP inputs)
+template <int FT, int NB, int NTW, int MODE>
 __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S, const TileSrc src,
                                                                  const float* __restrict__ grad_rgb,
                                                                  const TfShadeGrads G) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr bool WIDE = MODE == 1, BLDS = MODE == 0;
     constexpr int NT = 512, NW = 8, SG = NW / FT, NSW = 4 / SG;
     constexpr int FCc = 16 * FT, EA2 = FCc / 32, EB2 = FCc / 64, EA1 = FCc / 64;
 #ifndef TF_KTBW
@@ -511,8 +514,13 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of V are in LDS
         // basis fragments of the wave's first dV unit (P7), in flight across the barrier
         const int n_units = 4 * ((ktB + 3) >> 2);
+        // dV's A operand, the packed basis [16 NB][kpB] (+ 64 floats of tail), in LDS for P7 when it fits the X region (free
+        // once P6 has read X): every workgroup used to re-read its fragments from L2 for every chunk — 98 KB per chunk at
+        // config 2 on a CU that takes in ~17 B per cycle, and the second dV unit of waves 4..7 waited for them
+        const int basis_fl = 16 * NB * kpB + 64;
+        constexpr bool b_lds = BLDS;          // (the launch picks MODE 0 only when basis_fl <= M * sx: basis_in_lds())
         f32x4 bfr[4 * NB];
-        {
+        if constexpr (!b_lds) {
             const int u0 = NW - 1 - wave, r = lane & 15, kq = lane >> 4;
             const float* np = S.basis + (size_t)kq * kpB + 64 * (u0 >> 2) + 4 * r;
 #pragma unroll
@@ -527,6 +535,88 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
             lds_barrier();
         }
         TF_MARK(7);
+        if constexpr (b_lds) {
+            // ---- P7, basis in LDS: [basis DMA | dB tile 0] -> barrier -> next-chunk requests -> dV from LDS -> other dB tiles
+            float* BL = X;
+            for (int p = wave; 256 * p < basis_fl; p += NW)
+                if (256 * p + 4 * lane < basis_fl)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(S.basis + 256 * p + 4 * lane),
+                                                     (__attribute__((address_space(3))) void*)(BL + 256 * p), 16, 0, 0);
+            {
+                f32x4 (&tile)[NB][1] = reinterpret_cast<f32x4 (&)[NB][1]>(aB[0]);
+                if (wave < ktB) tn_block<NB, 1>(Fd, L.sf, 0, V, L.sv, 16 * wave, M / 4, tile, lane);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the basis are in LDS
+            lds_barrier();
+            {
+                Chunk c1;
+                if (locate_chunk(src, pre, v, v_end, c1)) fetch_x(c1, tid, true);
+                else n_g = n_c = 0.f;
+            }
+            TF_MARK(10);
+            {
+                const int r = lane & 15, kq = lane >> 4;
+                for (int u = NW - 1 - wave; u < n_units; u += NW) {
+                    const int st = u & 3, cb = 64 * (u >> 2);
+                    const float* bp = Fd + (16 * st + r) * L.sf + kq;
+                    const float* ap = BL + kq * kpB + cb + 4 * r;
+                    const int s = 16 * st + lc;
+                    f32x4 acc[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int h = 0; h < 4 * NB; h += 4) {      // four k-steps of operands at a time (16 + 4 registers)
+                        float bq[4];
+                        f32x4 af[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            bq[t] = bp[4 * (h + t)];
+                            af[t] = *reinterpret_cast<const f32x4*>(ap + 4 * (h + t) * kpB);
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][e], bq[t], acc[e], 0, 0, 0);
+                    }
+                    // The accumulators leave through a [16][64] tile of this wave in LDS (H1's space, or the X region
+                    // behind the basis): a lane holds 16 B pieces 64 B apart in FOUR rows' worth of lines per store
+                    // instruction — 64 partial lines — and the stores backed up into the issue (3.5 k cycles per unit);
+                    // read back row-wise, 16 lanes write 256 contiguous bytes.
+                    float* stg = wave < 5 ? H1 + wave * (16 * 68) : X + ((basis_fl + 3) & ~3) + (wave - 5) * (16 * 68);
+                    (void)s;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+                        *reinterpret_cast<f32x4*>(stg + lc * 68 + 16 * lg + 4 * reg) =
+                            (f32x4){acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]};
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; ++i4) {
+                        const int row = 4 * i4 + (lane >> 4), c = cb + 4 * (lane & 15), sr = 16 * st + row;
+                        const f32x4 val = *reinterpret_cast<const f32x4*>(stg + row * 68 + 4 * (lane & 15));
+                        if (sr < n) {
+                            float* o = dv + ck.at(sr) * nat;
+                            if (v_vec && c + 3 < nat) {
+                                *reinterpret_cast<f32x4*>(o + c) = val;
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (c + e < nat) o[c + e] = val[e];
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            TF_MARK(8);
+#pragma unroll
+            for (int k = 1; k < KTBW; ++k) {
+                f32x4 (&tile)[NB][1] = reinterpret_cast<f32x4 (&)[NB][1]>(aB[k]);
+                if (wave + NW * k < ktB) tn_block<NB, 1>(Fd, L.sf, 0, V, L.sv, 16 * (wave + NW * k), M / 4, tile, lane);
+            }
+        } else {
         // operands of the next chunk: its X rows go straight into the X region, which nothing reads any more (a WIDE V
         // tile lies over it: there the request waits until P7 is done)
         {
@@ -595,6 +685,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         for (int k = 0; k < KTBW; ++k) {
             f32x4 (&tile)[NB][1] = reinterpret_cast<f32x4 (&)[NB][1]>(aB[k]);
             if (wave + NW * k < ktB) tn_block<NB, 1>(Fd, L.sf, 0, V, L.sv, 16 * (wave + NW * k), M / 4, tile, lane);
+        }
         }
         first = false;
         TF_MARK(9);
@@ -776,27 +867,32 @@ __global__ __launch_bounds__(256) void app_direct_scatter_kernel(const TfShade S
 typedef void (*bwd_fn_t)(const TfShade, const TileSrc, const float*, const TfShadeGrads);
 
 template <int FT, int NB>
-bwd_fn_t pick_ntw(int ntw, bool wide) {
+bwd_fn_t pick_ntw(int ntw, int mode) {
     switch (ntw) {
-        case 2: return wide ? shade_backward_kernel<FT, NB, 2, true> : shade_backward_kernel<FT, NB, 2, false>;
-        case 4: return wide ? shade_backward_kernel<FT, NB, 4, true> : shade_backward_kernel<FT, NB, 4, false>;
-        case 5: return wide ? shade_backward_kernel<FT, NB, 5, true> : shade_backward_kernel<FT, NB, 5, false>;
-        case 6: return wide ? shade_backward_kernel<FT, NB, 6, true> : shade_backward_kernel<FT, NB, 6, false>;
+        case 2: return mode == 1 ? shade_backward_kernel<FT, NB, 2, 1> : (mode == 0 ? shade_backward_kernel<FT, NB, 2, 0> : shade_backward_kernel<FT, NB, 2, 2>);
+        case 4: return mode == 1 ? shade_backward_kernel<FT, NB, 4, 1> : (mode == 0 ? shade_backward_kernel<FT, NB, 4, 0> : shade_backward_kernel<FT, NB, 4, 2>);
+        case 5: return mode == 1 ? shade_backward_kernel<FT, NB, 5, 1> : (mode == 0 ? shade_backward_kernel<FT, NB, 5, 0> : shade_backward_kernel<FT, NB, 5, 2>);
+        case 6: return mode == 1 ? shade_backward_kernel<FT, NB, 6, 1> : (mode == 0 ? shade_backward_kernel<FT, NB, 6, 0> : shade_backward_kernel<FT, NB, 6, 2>);
     }
     return nullptr;
 }
 
 bwd_fn_t pick_bwd(const TfShade& S) {
 #ifdef TF_ONLY_C2     // compile-time experiments: the benchmark configuration only
-    return shade_backward_kernel<8, 2, 5, false>;
+    return shade_backward_kernel<8, 2, 5, 0>;
 #else
     const int nb = (S.app_dim + 15) / 16, kt1 = kpad16(S.in_c) / 16;
     if (S.head != TF_HEAD_MLP || nb > 2 || kt1 > 12 || kpad16(S.n_app_total) / 16 > 24) return nullptr;
     const BwdLds L = bwd_lds(S);
     if (!bwd_lds_ok(S, L)) return nullptr;
     const int ntw = ntw_of(kt1);
-    if (S.feature_c == 64) return nb == 1 ? pick_ntw<4, 1>(ntw, L.wide) : pick_ntw<4, 2>(ntw, L.wide);
-    if (S.feature_c == 128) return nb == 1 ? pick_ntw<8, 1>(ntw, L.wide) : pick_ntw<8, 2>(ntw, L.wide);
+    // the basis image of P7 (16 nb rows of kpad16(n_app_total) floats + 64 of tail) in the X region?
+    // ... and the dV staging tiles (16 x 68 floats per wave: five in H1's space, three behind the basis)?
+    const int basis_fl = 16 * nb * kpad16(S.n_app_total) + 64;
+    const bool basis_fits = ((basis_fl + 3) & ~3) + 3 * 16 * 68 <= M * L.sx && 5 * 16 * 68 <= M * L.sh;
+    const int mode = L.wide ? 1 : (basis_fits ? 0 : 2);
+    if (S.feature_c == 64) return nb == 1 ? pick_ntw<4, 1>(ntw, mode) : pick_ntw<4, 2>(ntw, mode);
+    if (S.feature_c == 128) return nb == 1 ? pick_ntw<8, 1>(ntw, mode) : pick_ntw<8, 2>(ntw, mode);
     return nullptr;
 #endif
 }
