@@ -466,46 +466,67 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         if (!WIDE && v_vec)      // V rows of this chunk: global -> LDS by DMA, landing behind the dfeat arithmetic
             dma_rows(dv, vq4, V, svq, inv_svq, n, wave, lane, [&](int r) { return ck.at(r); });
         {   // dfeat = dX[:, :D] + PE'(feat): d/dx [sin(x 2^k) m_s] = cos(.) 2^k m_s,  d/dx [cos(.) m_c] = -sin(.) 2^k m_c
-            for (int it = tid; it < M * 16 * NB; it += NT) {
-                const int smp = it / (16 * NB), d = it % (16 * NB);
-                float gsum = 0.f;
-                if (d < S.app_dim) {
-                    const float* dx = DX + smp * L.sx;
-                    gsum = dx[d];
-                    int off = S.app_dim + 3;
-                    for (int b = 0; b < S.n_pe; ++b) {
-                        const int F = S.pe[b].freqs;
-                        const int D = S.pe[b].src == TF_SRC_FEAT ? S.app_dim : 3;
-                        if (S.pe[b].src == TF_SRC_FEAT) {
-                            const float* mk = S.pe[b].mask;
-                            const float fv = X[smp * L.sx + d];
+            // Thread -> column d = tid % (16 NB) of the samples tid / (16 NB) + SPP i: the SI samples of a thread advance
+            // together through the encoding terms, so SI independent LDS reads are in flight per term (sample by sample the
+            // phase was a chain of LDS latencies: runtime loop bounds, one accumulator).  Same terms, same order per sample.
+            constexpr int DC = 16 * NB, SPP = NT / DC, SI = M / SPP;
+            const int d = tid % DC, s0 = tid / DC;
+            float gsum[SI];
+#pragma unroll
+            for (int i = 0; i < SI; ++i) gsum[i] = 0.f;
+            if (d < S.app_dim) {
+#pragma unroll
+                for (int i = 0; i < SI; ++i) gsum[i] = DX[(s0 + SPP * i) * L.sx + d];
+                int off = S.app_dim + 3;
+                for (int b = 0; b < S.n_pe; ++b) {
+                    const int F = S.pe[b].freqs;
+                    const int D = S.pe[b].src == TF_SRC_FEAT ? S.app_dim : 3;
+                    if (S.pe[b].src == TF_SRC_FEAT) {
+                        const float* mk = S.pe[b].mask;
+                        if (!mk) {     // unmasked: X's PE columns ARE sin / cos of these arguments (saved by the forward)
                             float fr = 1.f;
-                            const bool big = !(ldexpf(fabsf(fv), F - 1) < 8192.f);
-                            if (!mk) {     // unmasked: X's PE columns ARE sin / cos of these arguments (saved by the forward)
-                                const float* xr = X + smp * L.sx + off;
-                                for (int k = 0; k < F; ++k) {
-                                    const int ci = d * F + k;
-                                    gsum += dx[off + ci] * (xr[D * F + ci] * fr);
-                                    gsum -= dx[off + D * F + ci] * (xr[ci] * fr);
-                                    fr *= 2.f;
+                            for (int k = 0; k < F; ++k) {
+                                const int ci = d * F + k;
+                                float a0[SI], a1[SI], c0[SI], c1[SI];
+#pragma unroll
+                                for (int i = 0; i < SI; ++i) {
+                                    const int row = (s0 + SPP * i) * L.sx;
+                                    a0[i] = DX[row + off + ci];
+                                    c0[i] = X[row + off + D * F + ci];
+                                    a1[i] = DX[row + off + D * F + ci];
+                                    c1[i] = X[row + off + ci];
                                 }
-                            } else {
+#pragma unroll
+                                for (int i = 0; i < SI; ++i) {
+                                    gsum[i] += a0[i] * (c0[i] * fr);
+                                    gsum[i] -= a1[i] * (c1[i] * fr);
+                                }
+                                fr *= 2.f;
+                            }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < SI; ++i) {
+                                const int row = (s0 + SPP * i) * L.sx;
+                                const float fv = X[row + d];
+                                const bool big = !(ldexpf(fabsf(fv), F - 1) < 8192.f);
+                                float fr = 1.f;
                                 for (int k = 0; k < F; ++k) {
                                     float sn, cs;
                                     if (__builtin_expect(big, 0)) pe_sincos(fv * fr, &sn, &cs);
                                     else pe_sincos_fast(fv * fr, &sn, &cs);
                                     const int ci = d * F + k;
-                                    gsum += dx[off + ci] * (cs * fr * mk[ci]);
-                                    gsum -= dx[off + D * F + ci] * (sn * fr * mk[D * F + ci]);
+                                    gsum[i] += DX[row + off + ci] * (cs * fr * mk[ci]);
+                                    gsum[i] -= DX[row + off + D * F + ci] * (sn * fr * mk[D * F + ci]);
                                     fr *= 2.f;
                                 }
                             }
                         }
-                        off += 2 * D * F;
                     }
+                    off += 2 * D * F;
                 }
-                Fd[smp * L.sf + d] = gsum;
             }
+#pragma unroll
+            for (int i = 0; i < SI; ++i) Fd[(s0 + SPP * i) * L.sf + d] = gsum[i];
         }
         if (!WIDE && !v_vec) {
             for (int smp = wave; smp < M; smp += NW)
