@@ -350,6 +350,13 @@ __global__ __launch_bounds__(256) void composite_kernel(int n_rays, const int* _
     }
     const int r = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
     float c[3] = {0.f, 0.f, 0.f};
+    // what the ray's result is combined with is requested up front, beside the sample loads (read where it is used, each
+    // was one more memory round trip on a kernel that is little else)
+    float acc_r = 0.f, tgt = 0.f;
+    if (r < n_rays && sub < 3) {
+        if (white_bg) acc_r = acc[r];
+        if (L.target) tgt = L.target[(size_t)r * 3 + sub];
+    }
     if (r < n_rays) {
         const int o = app_offset[r], n = app_count[r];
         for (int k = sub; k < n; k += 8) {
@@ -369,13 +376,13 @@ __global__ __launch_bounds__(256) void composite_kernel(int n_rays, const int* _
     float d2 = 0.f;
     if (r < n_rays && sub < 3) {
         float v = sub == 0 ? c[0] : (sub == 1 ? c[1] : c[2]);
-        if (white_bg) v += 1.f - acc[r];
+        if (white_bg) v += 1.f - acc_r;
         if (rgb_pre) rgb_pre[(size_t)r * 3 + sub] = v;
         const float o = fminf(fmaxf(v, 0.f), 1.f);
         rgb_map[(size_t)r * 3 + sub] = o;
         if (L.target) {      // loss = mean((rgb_map - target)^2) and its gradient (train.py:334), as mse_grad_kernel
             const float inv = 1.f / (float)(3 * n_rays);
-            const float d = o - L.target[(size_t)r * 3 + sub];
+            const float d = o - tgt;
             d2 = d * d;
             L.grad[(size_t)r * 3 + sub] = 2.f * d * inv * L.grad_scale;
         }
