@@ -117,13 +117,23 @@ BIN_MAX_KEYS = 262144     # TF_BIN_MAX_KEYS: tf_binned_scatter rejects jobs with
 
 
 class TfAdamSeg(C.Structure):
-    _fields_ = [("p", _fp), ("g", _fp), ("m", _fp), ("v", _fp), ("n", C.c_longlong), ("group", C.c_int), ("pad_", C.c_int)]
+    _fields_ = [("p", _fp), ("g", _fp), ("m", _fp), ("v", _fp), ("n", C.c_longlong), ("group", C.c_int), ("gate", C.c_int)]
 
 
 class TfAdamJob(C.Structure):
     _fields_ = [("n_seg", C.c_int), ("clear_grads", C.c_int), ("seg", TfAdamSeg * ADAM_MAX_SEG),
                 ("chunk_end", C.c_int * ADAM_MAX_SEG), ("lrs", _fp), ("step", _fp),
-                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("step_rw", _fp), ("arrivals", _fp), ("touched", _fp)]
+                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("arrivals", _fp), ("touched", _fp),
+                ("live", _fp), ("reg_active", _fp), ("skip_mask", C.c_uint), ("pad_", C.c_int)]
+
+
+# TfAdamSeg.gate: which sample count opens a segment (TfLive) and which regulariser terms force it open
+GATE_DENSITY, GATE_SHADED = 1, 2
+REG_ORTHO, REG_L1, REG_TV_DENSITY, REG_TV_APP = 1 << 4, 2 << 4, 4 << 4, 8 << 4
+
+
+class TfLive(C.Structure):
+    _fields_ = [("dev", _fp), ("host", _fp)]
 
 
 class HipError(RuntimeError):
@@ -145,8 +155,9 @@ _SIGS = {
     "tf_generate_rays": [C.POINTER(TfCamera), _fp, C.c_longlong, C.c_int, _fp, _fp],
     "tf_march_forward": [C.POINTER(TfField), C.POINTER(TfMarchIO), _fp],
     "tf_shade_forward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, C.c_int, C.POINTER(TfShadeSave), _fp],
-    "tf_composite_forward": [C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp, _fp, _fp],
-    "tf_composite_forward_loss": [C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp, _fp, C.POINTER(TfLossFuse), _fp],
+    "tf_composite_forward": [C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp, _fp, C.POINTER(TfLive), _fp],
+    "tf_composite_forward_loss": [C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp, _fp, C.POINTER(TfLossFuse),
+                                  C.POINTER(TfLive), _fp],
     "tf_density_points": [C.POINTER(TfField), _fp, C.c_int, _fp, _fp],
     "tf_appfeature_points": [C.POINTER(TfShade), _fp, C.c_int, _fp, _fp],
     "tf_shade_points": [C.POINTER(TfShade), _fp, _fp, _fp, C.c_int, _fp, _fp],

@@ -158,8 +158,18 @@ class _RenderFn(torch.autograd.Function):
         if g_rgb is None:
             g_rgb = torch.zeros(c['ws'].R, 3, dtype=torch.float32, device=ctx.params[0].device)
         early, ctx.early_bufs = ctx.early_bufs, None
+        slot = c.get('live_slot')
         grads = backward_launches(model, c, named, g_rgb, early, "all")
-        out = tuple(grads[n] if p.requires_grad else None for n, p in named)
+        n_density = n_shaded = 1
+        if slot is not None:
+            # The parameters the reference's autograd graph would not contain get no gradient here either: density factors
+            # without a valid sample (tensorBase.py:359), appearance factors / basis / MLP without a shaded one (:370).  The
+            # counts were written to pinned memory by the forward's compositing launch; its event has usually fired by now
+            # (the wait is on the forward only, the backward launches above are already queued).
+            slot[1].synchronize()
+            n_density, n_shaded = slot[0].tolist()
+        out = tuple((grads[n] if (n_density if n.startswith('density_') else n_shaded) else None) if p.requires_grad else None
+                    for n, p in named)
         ctx.c = None
         return (None,) * 8 + out
 
@@ -248,5 +258,6 @@ def render_with_grad(model, rays, mask, white_bg, is_train, ndc_ray, N_samples):
     cache = model._named_cache
     if cache is None or cache[2] != sig:
         named = list(model.named_parameters())
+        model._tag_parameters(named)
         cache = model._named_cache = (tuple(n for n, _ in named), [p for _, p in named], sig)
     return _RenderFn.apply(model, rays, mask, white_bg, is_train, ndc_ray, N_samples, cache[0], *cache[1])

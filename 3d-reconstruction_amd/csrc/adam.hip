@@ -14,6 +14,30 @@ namespace {
 constexpr int kChunk = TF_ADAM_CHUNK;   // elements per workgroup
 static_assert(TF_ADAM_CHUNK == 8192, "the touched word holds 4 waves x 8 rounds of 256 floats");
 
+// Is segment s updated by this launch?  (TfAdamJob: host skip mask, sample-count gate, regulariser flags.)
+__device__ __forceinline__ bool seg_open(const TfAdamJob& J, int s) {
+    if ((J.skip_mask >> s) & 1u) return false;
+    const int gate = J.seg[s].gate;
+    const int cnt = gate & 3;
+    if (!cnt || !J.live) return true;
+    if (J.live[cnt - 1] != 0.f) return true;
+    if (J.reg_active) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            if (((gate >> (4 + b)) & 1) && J.reg_active[b] != 0.f) return true;
+    }
+    return false;
+}
+
+// Last workgroup of the launch: advance the counts of the updated segments, re-arm the arrival counter.
+__device__ __forceinline__ void arrive(const TfAdamJob& J) {
+    if (atomicAdd(J.arrivals, 1u) == gridDim.x - 1) {
+        for (int s = 0; s < J.n_seg; ++s)
+            if (seg_open(J, s)) J.step[s] = J.step[s] + 1.f;
+        *J.arrivals = 0u;
+    }
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(const TfAdamJob J) {
     __shared__ float s_hyp[2];
     __shared__ int s_seg;
@@ -21,13 +45,18 @@ __global__ __launch_bounds__(256) void adam_kernel(const TfAdamJob J) {
     if (tid == 0) {
         int s = 0;
         while (s + 1 < J.n_seg && (int)blockIdx.x >= J.chunk_end[s]) ++s;
-        s_seg = s;
-        const double t = (double)*J.step + 1.0;      // *step counts the completed updates; this one is number t
+        const bool open = seg_open(J, s);
+        s_seg = open ? s : -1;
+        const double t = (double)J.step[s] + 1.0;    // step[s] counts the segment's completed updates; this is number t
         const double bc1 = 1.0 - pow(J.beta1, t), bc2 = 1.0 - pow(J.beta2, t);
         s_hyp[0] = (float)((double)J.lrs[J.seg[s].group] / (double)(float)bc1);   // step size
         s_hyp[1] = (float)sqrt(bc2);
     }
     __syncthreads();
+    if (s_seg < 0) {         // a parameter without a gradient this step: untouched, like torch.optim.Adam's `grad is None`
+        if (tid == 0) arrive(J);
+        return;
+    }
     const TfAdamSeg& sg = J.seg[s_seg];
     const float step_size = s_hyp[0], bc2_sqrt = s_hyp[1];
     const long long c0 = (long long)((int)blockIdx.x - (s_seg ? J.chunk_end[s_seg - 1] : 0)) * kChunk;
@@ -106,24 +135,19 @@ __global__ __launch_bounds__(256) void adam_kernel(const TfAdamJob J) {
         upd(p[i], g[i], m[i], v[i]);
         if (J.clear_grads) g[i] = 0.f;
     }
-    // every workgroup has read *step by now or will have before it arrives here: the last one to arrive advances the
-    // count for the next launch and re-arms the arrival counter (no separate "step += 1" launch per update)
-    if (J.arrivals) {
-        __syncthreads();
-        if (tid == 0) {     // (thread 0 consumed *step before the first barrier of this workgroup: no fence needed,
-                            //  and a device-scope fence here would write back the L2 once per workgroup)
-            if (atomicAdd(J.arrivals, 1u) == gridDim.x - 1) {
-                *J.step_rw = *J.step + 1.f;
-                *J.arrivals = 0u;
-            }
-        }
-    }
+    // every workgroup has read its step count by now or will have before it arrives here: the last one to arrive advances
+    // the counts for the next launch and re-arms the arrival counter (no separate "step += 1" launch per update)
+    __syncthreads();
+    // (thread 0 consumed step[] before the first barrier of this workgroup: no fence needed, and a device-scope fence
+    //  here would write back the L2 once per workgroup)
+    if (tid == 0) arrive(J);
 }
 
 }  // namespace
 
 extern "C" int tf_adam_step(const TfAdamJob* job, tf_stream_t stream) {
-    if (job->n_seg < 1 || job->n_seg > TF_ADAM_MAX_SEG || !job->lrs || !job->step) return (int)hipErrorInvalidValue;
+    if (job->n_seg < 1 || job->n_seg > TF_ADAM_MAX_SEG || !job->lrs || !job->step || !job->arrivals)
+        return (int)hipErrorInvalidValue;
     for (int s = 0; s < job->n_seg; ++s) {
         const TfAdamSeg& sg = job->seg[s];
         // 16-B lanes: every stream of a segment must be 16-B aligned

@@ -342,11 +342,30 @@ __global__ __launch_bounds__(256) void composite_kernel(int n_rays, const int* _
                                                         int white_bg, float* __restrict__ rgb_map,
                                                         float* __restrict__ rgb_pre,
                                                         const int* __restrict__ counters,
-                                                        long long* __restrict__ n_shaded, const TfLossFuse L) {
-    if (n_shaded && blockIdx.x == 0 && threadIdx.x == 0) {     // num_valid_samples = app_mask.sum()  (tensorBase.py:390)
-        long long t = 0;
-        for (int g = 0; g < kShards; ++g) t += counters[g * kShardStride];
-        *n_shaded = t;
+                                                        long long* __restrict__ n_shaded, const TfLossFuse L,
+                                                        const TfLive live) {
+    if ((n_shaded || live.dev || live.host) && blockIdx.x == 0 && threadIdx.x < 64) {
+        // num_valid_samples = app_mask.sum() (tensorBase.py:390); and the step's sample counts for the optimizer's gates
+        // and the autograd binding: ray_valid.any() / app_mask.any() decide which parameters the reference's graph holds
+        // (tensorBase.py:359, :370)
+        long long shaded = counters[threadIdx.x * kShardStride], density = counters[threadIdx.x * kShardStride + 1];
+        static_assert(kShards == 64, "one shard per lane");
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            shaded += __shfl_xor(shaded, o, 64);
+            density += __shfl_xor(density, o, 64);
+        }
+        if (threadIdx.x == 0) {
+            if (n_shaded) *n_shaded = shaded;
+            if (live.dev) {
+                live.dev[0] = (float)density;
+                live.dev[1] = (float)shaded;
+            }
+            if (live.host) {
+                live.host[0] = (int)(density > 0x7fffffff ? 0x7fffffff : density);
+                live.host[1] = (int)(shaded > 0x7fffffff ? 0x7fffffff : shaded);
+            }
+        }
     }
     const int r = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
     float c[3] = {0.f, 0.f, 0.f};
@@ -475,21 +494,23 @@ int tf_march_forward(const TfField* field, const TfMarchIO* io, tf_stream_t stre
 
 int tf_composite_forward(int n_rays, const int* app_offset, const int* app_count, const float* app_w,
                          const float* rgb, const float* acc, int white_bg, float* rgb_map, float* rgb_pre,
-                         const int* counters, long long* n_shaded, tf_stream_t stream) {
+                         const int* counters, long long* n_shaded, const TfLive* live, tf_stream_t stream) {
     if (n_rays <= 0) return 0;
     hipLaunchKernelGGL(composite_kernel, dim3((n_rays + 31) / 32), dim3(256), 0, (hipStream_t)stream, n_rays,
                        app_offset, app_count, app_w, rgb, acc, white_bg, rgb_map, rgb_pre, counters, n_shaded,
-                       TfLossFuse{nullptr, 0.f, nullptr, nullptr, nullptr});
+                       TfLossFuse{nullptr, 0.f, nullptr, nullptr, nullptr}, live ? *live : TfLive{nullptr, nullptr});
     return TF_CHECK_LAUNCH();
 }
 
 int tf_composite_forward_loss(int n_rays, const int* app_offset, const int* app_count, const float* app_w,
                               const float* rgb, const float* acc, int white_bg, float* rgb_map, float* rgb_pre,
-                              const int* counters, long long* n_shaded, const TfLossFuse* fuse, tf_stream_t stream) {
+                              const int* counters, long long* n_shaded, const TfLossFuse* fuse, const TfLive* live,
+                              tf_stream_t stream) {
     if (n_rays <= 0) return 0;
     if (!fuse || !fuse->target || !fuse->grad || !fuse->loss || !fuse->state) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(composite_kernel, dim3((n_rays + 31) / 32), dim3(256), 0, (hipStream_t)stream, n_rays,
-                       app_offset, app_count, app_w, rgb, acc, white_bg, rgb_map, rgb_pre, counters, n_shaded, *fuse);
+                       app_offset, app_count, app_w, rgb, acc, white_bg, rgb_map, rgb_pre, counters, n_shaded, *fuse,
+                       live ? *live : TfLive{nullptr, nullptr});
     return TF_CHECK_LAUNCH();
 }
 

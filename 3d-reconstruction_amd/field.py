@@ -285,6 +285,14 @@ class TensorBase(nn.Module):
         self._loss_fuse = None         # GraphedTrainStep: TfLossFuse — the compositing launch also forms the loss and its gradient
         self.static_jitter = None      # graph capture: device tensor (R,) the harness refills before every replay
         self._debug_masks = False      # tests: also emit the bbox / valid bitmaps
+        # The reference's graph holds the density factors only `if ray_valid.any()` and the appearance factors, basis and
+        # MLP only `if app_mask.any()` (tensorBase.py:359, :370): in a step without such samples (the first iterations of a
+        # fresh field) their .grad stays None and torch.optim.Adam skips them — no moment decay, no step count.  True: the
+        # eager autograd path returns None for those gradients too (one event wait on the forward per backward; single
+        # process only).  FusedAdam gets the same behaviour from the device-side counts (`_live`, TfAdamJob.live).
+        self.reference_none_grads = True
+        self._live = None              # device float[2]: density / shaded samples of the last training forward (TfLive.dev)
+        self._live_ring, self._live_i = None, 0     # pinned int32[2] + event per training forward in flight (TfLive.host)
         self._ws_cache = {}
         self._train_ws = {}
         self._named_cache = None
@@ -364,6 +372,34 @@ class TensorBase(nn.Module):
             self.alphaMask = AlphaGridMask(self.device, ckpt['alphaMask.aabb'].to(self.device),
                                            alpha_volume.float().to(self.device))
         self.load_state_dict(ckpt['state_dict'])
+
+    # ---- which parameters a step without samples leaves without a gradient (TfAdamSeg.gate) ------------
+    def _live_counts(self, dev):
+        if self._live is None or self._live.device != torch.device(dev):
+            self._live = torch.ones(2, dtype=torch.float32, device=dev)
+        return self._live
+
+    def _gate_of(self, name):
+        cp = self._is_cp()
+        if name.startswith('density_plane'):
+            return H.GATE_DENSITY | H.REG_L1 | H.REG_TV_DENSITY                  # tensoRF.py:190-205
+        if name.startswith('density_line'):
+            return H.GATE_DENSITY | H.REG_L1 | (H.REG_TV_DENSITY if cp else H.REG_ORTHO)
+        if name.startswith('app_plane'):
+            return H.GATE_SHADED | H.REG_TV_APP
+        if name.startswith('app_line'):
+            return H.GATE_SHADED | (H.REG_TV_APP if cp else H.REG_ORTHO)
+        return H.GATE_SHADED                                                      # basis_mat, renderModule
+
+    def _tag_parameters(self, named=None):
+        """Marks every parameter with (the model's sample-count words, its gate): FusedAdam reads the tag when it builds
+        its launch descriptors.  Called wherever parameter objects are handed out or replaced."""
+        named = list(self.named_parameters()) if named is None else named
+        if not named or not named[0][1].is_cuda:
+            return
+        live = self._live_counts(named[0][1].device)
+        for n, p in named:
+            p._tf_gate = (live, self._gate_of(n))
 
     # ---- kernel descriptors -------------------------------------------------------------------
     def _is_cp(self):
@@ -814,19 +850,47 @@ class TensorBase(nn.Module):
                     ws.rgb.data_ptr(), self.shade_wgs_beside_sort if sorted_on is not None else 0,
                     C.byref(save) if save is not None else None, st)
         fuse = self._loss_fuse if save_valid else None     # graph.GraphedTrainStep: loss + its gradient in the same launch
+        live, live_slot = None, None
+        if save_valid:          # the step's sample counts: device words for FusedAdam's gates, pinned words for autograd
+            live = H.TfLive()
+            live.dev = self._live_counts(dev).data_ptr()
+            live_slot = self._live_slot()
+            if live_slot is not None:
+                live.host = live_slot[0].data_ptr()
         if fuse is not None:
             self._timed("tf_composite_forward", lib.tf_composite_forward_loss, R, ws.app_offset.data_ptr(),
                         ws.app_count.data_ptr(), ws.app_w.data_ptr(), ws.rgb.data_ptr(), ws.acc.data_ptr(), int(use_bg),
-                        out_rgb.data_ptr(), ws.rgb_pre.data_ptr(), ws.counters.data_ptr(), H.ptr(out_n), C.byref(fuse), st)
+                        out_rgb.data_ptr(), ws.rgb_pre.data_ptr(), ws.counters.data_ptr(), H.ptr(out_n), C.byref(fuse),
+                        C.byref(live) if live is not None else None, st)
         else:
             self._timed("tf_composite_forward", lib.tf_composite_forward, R, ws.app_offset.data_ptr(),
                         ws.app_count.data_ptr(), ws.app_w.data_ptr(), ws.rgb.data_ptr(), ws.acc.data_ptr(), int(use_bg),
                         out_rgb.data_ptr(), ws.rgb_pre.data_ptr() if save_valid else None, ws.counters.data_ptr(),
-                        H.ptr(out_n), st)
+                        H.ptr(out_n), C.byref(live) if live is not None else None, st)
+        if live_slot is not None:
+            if R > 0:
+                live_slot[1].record()
+            else:               # (the compositing kernel does not launch for an empty batch)
+                live_slot[0].zero_()
         ctx = dict(ws=ws, rgb_map=out_rgb, depth=out_depth, rays=rays, field=field, shade=shade, io=io, keep=(keep, den_masks, app_masks, jitter, ztab),
-                   use_bg=use_bg, ndc=bool(ndc_ray), sorted_on=sorted_on, n_shaded=out_n)
+                   use_bg=use_bg, ndc=bool(ndc_ray), sorted_on=sorted_on, n_shaded=out_n, live_slot=live_slot)
         self.last = ctx
         return ctx
+
+    def _live_slot(self):
+        """(pinned int32[2], event) for this training forward's sample counts, or None when nobody will read them on the
+        host: inside a graph capture, with `reference_none_grads` off, or in a multi-process group (a rank cannot drop a
+        gradient the other ranks exchange; there the device-side counts are summed with the gradients, parallel.py)."""
+        if not self.reference_none_grads or torch.cuda.is_current_stream_capturing():
+            return None
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return None
+        if self._live_ring is None:
+            self._live_ring = [(torch.zeros(2, dtype=torch.int32).pin_memory(), torch.cuda.Event()) for _ in range(8)]
+        slot = self._live_ring[self._live_i % len(self._live_ring)]
+        self._live_i += 1
+        return slot
 
     def forward(self, rays_chunk, mask, white_bg=True, is_train=False, ndc_ray=False, N_samples=-1):
         """models/tensorBase.py:321-395: returns (rgb_map (R,3), depth_map (R,), num_valid_samples)."""
@@ -1023,6 +1087,7 @@ class TensorVMSplit(TensorBase):
                      {'params': self.basis_mat.parameters(), 'lr': lr_init_network}]
         if isinstance(self.renderModule, nn.Module):
             grad_vars += [{'params': self.renderModule.parameters(), 'lr': lr_init_network}]
+        self._tag_parameters()
         return grad_vars
 
 
@@ -1115,6 +1180,7 @@ class TensorCP(TensorBase):
                      {'params': self.basis_mat.parameters(), 'lr': lr_init_network}]
         if isinstance(self.renderModule, nn.Module):
             grad_vars += [{'params': self.renderModule.parameters(), 'lr': lr_init_network}]
+        self._tag_parameters()
         return grad_vars
 
     def density_L1(self):

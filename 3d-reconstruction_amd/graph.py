@@ -130,6 +130,8 @@ class GraphedTrainStep:
     def set_regularizer_weights(self, ortho=0.0, l1=0.0, tv_density=0.0, tv_app=0.0):
         """Weights of the four regulariser terms for the next step(s) (needs regularizers=True)."""
         vals = [float(ortho), float(l1), float(tv_density), float(tv_app)]
+        if hasattr(self.opt, "set_regularizer_activity"):     # terms that are on give their tensors a gradient in every step
+            self.opt.set_regularizer_activity(*[v > 0 for v in vals])
         if vals != self._regw_host:
             self._regw.copy_(torch.tensor(vals).pin_memory(), non_blocking=True)
             self._regw_host = vals
@@ -206,11 +208,15 @@ class GraphedTrainStep:
     # packing of the rows that travel (tf_gather_rows) closes graphs (a) and (b), their write-back opens graph (c)
     def _part_a(self):
         self._fwd_density()
-        self._items_d = parallel.bucket_gather(self.model, "density") if self._dist else []
+        # direct-scatter mode (binned_scatter off, or more keys than the sort's tables hold): the density LINE gradients
+        # still sit in their replicas when the density stage ends — tf_reduce_replicas folds them into the buffer only at
+        # the end of the shading stage — so nothing may travel yet: one bucket ("all") after the whole backward
+        self._one_bucket = self._ctx[0]['ws'].binned_cfg is None
+        self._items_d = parallel.bucket_gather(self.model, "density") if (self._dist and not self._one_bucket) else []
 
     def _part_b(self):
         self._shade_half()
-        self._items_r = parallel.bucket_gather(self.model, "rest") if self._dist else []
+        self._items_r = parallel.bucket_gather(self.model, "all" if self._one_bucket else "rest") if self._dist else []
 
     def _part_c(self):
         parallel.bucket_writeback(self.model, self._items_d + self._items_r)    # (gradients are pre-divided by the world size)

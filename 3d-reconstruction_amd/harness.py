@@ -123,6 +123,8 @@ def train(tensorf, allrays, allrgbs, cfg=None, device="cuda", rank=0, world=1, l
                 rays_train, tensorf, mask, chunk=batch, N_samples=nSamples, white_bg=c["white_bg"], ndc_ray=c["ndc_ray"],
                 device=device, is_train=True)
             loss = torch.mean((rgb_map - rgb_train) ** 2)
+            if hasattr(opt, "set_regularizer_activity"):    # (FusedAdam: these terms open the factor tensors' gates)
+                opt.set_regularizer_activity(use_ortho > 0, l1_w > 0, tv_d > 0, tv_a > 0)
             if c.get("fused_regularizers", True) and fused_supported(tensorf):
                 # train.py:340-371 in one pass over the factor tensors (tf_regularizers): the terms do not depend on the
                 # rays, so their gradient is added after the data gradients have been reduced across ranks

@@ -176,6 +176,7 @@ def allreduce_gradients(model, group=None, average=True, use_support=True):
     world = dist.get_world_size(group)
     if world == 1 and not FORCE_EXCHANGE:
         return
+    _allreduce_live(model, group)
     flat = getattr(model, "grad_flat", None)
     params = [p for p in model.parameters() if p.grad is not None]
     owned = flat is not None and all(p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
@@ -227,6 +228,15 @@ def allreduce_gradients(model, group=None, average=True, use_support=True):
         off += n
 
 
+def _allreduce_live(model, group=None):
+    """The step's sample counts (field.TensorBase._live: density / shaded samples, the optimizer's gates) summed like the
+    gradients: a tensor group is updated when ANY rank had samples for it — what a single process with the whole batch
+    would do — and every rank takes the same decision."""
+    live = getattr(model, "_live", None)
+    if live is not None:
+        dist.all_reduce(live, op=dist.ReduceOp.SUM, group=group)
+
+
 # ---- bucketed, overlapped exchange (SURVEY §8e) -------------------------------------------------------------------
 # The backward finishes the density factors' gradients (tf_march_backward + density scatter) before it starts the
 # shading backward and the appearance scatter — 0.33 ms of the 0.45 ms backward at config 2.  The exchange therefore
@@ -272,8 +282,10 @@ def _bucket_rows(model):
 
 def bucket_gather(model, part):
     """First third of a bucket's exchange, launches only (capturable in a hipGraph): the pieces of model.grad_flat that
-    travel for part "density" / "rest" — with an alpha mask the rows that can be non-zero, gathered into a packed buffer
-    (tf_gather_rows), else slices of the buffer itself.  Returns [(tensor to all-reduce, row index | None, row width)]."""
+    travel for part "density" / "rest" / "all" — with an alpha mask the rows that can be non-zero, gathered into a packed
+    buffer (tf_gather_rows), else slices of the buffer itself.  Returns [(tensor to all-reduce, row index | None, row width)].
+    ("all": one bucket after the whole backward — the direct-scatter mode, whose line gradients are only folded out of
+    their replicas at the very end, tf_reduce_replicas.)"""
     flat = model.grad_flat
     br = _bucket_rows(model)
     items = []
@@ -281,16 +293,18 @@ def bucket_gather(model, part):
         from . import _hip as H
         from .field import _stream
         w, idx_d, idx_r = br
-        idx = idx_d if part == "density" else idx_r
-        if idx.numel():
-            buf = torch.empty(idx.numel(), w, dtype=torch.float32, device=flat.device)
-            H.check(H.lib().tf_gather_rows(flat.data_ptr(), idx.data_ptr(), idx.numel(), w, buf.data_ptr(), _stream()),
-                    "tf_gather_rows")
-            items.append((buf, idx, w))
+        for idx in ((idx_d,) if part == "density" else (idx_r,) if part == "rest" else (idx_d, idx_r)):
+            if idx.numel():
+                buf = torch.empty(idx.numel(), w, dtype=torch.float32, device=flat.device)
+                H.check(H.lib().tf_gather_rows(flat.data_ptr(), idx.data_ptr(), idx.numel(), w, buf.data_ptr(), _stream()),
+                        "tf_gather_rows")
+                items.append((buf, idx, w))
     else:
         dens, rest = _bucket_segments(model)
-        for a, b in (dens if part == "density" else rest):
+        for a, b in (dens if part == "density" else rest if part == "rest" else sorted(dens + rest)):
             items.append((flat[a:b], None, 0))
+    if part != "density" and getattr(model, "_live", None) is not None:
+        items.append((model._live, None, 0))      # the sample counts behind the optimizer's gates travel with the gradients
     return items
 
 

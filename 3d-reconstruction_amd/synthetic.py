@@ -122,3 +122,51 @@ def tt_rays(n_rays, aabb, seed=11):
     z = torch.arange(n_rays) % 64 == 0
     d[z, 2] = 0.0
     return torch.cat([o, d], 1).float()
+
+
+# ---- BASELINE.json's five configurations as seeded synthetic scenes (bench.py --config, tests/test_full_size.py)
+TT_AABB = [[-2.4, -1.6, -1.9], [2.2, 1.7, 1.3]]
+BASELINE_SCENES = ("C1_vm128", "C2_vm300", "C3_cp300_sh", "C3_cp300_mlp", "C4_ndc", "C5_tt640")
+
+
+def baseline_scene(name, device, n_rays=None, views=1):
+    """(model, rays (on the CPU), n_samples, ndc_ray, white_bg) of one BASELINE configuration at its full size, in the
+    'trained-like' state:
+      C1_vm128      configs/lego.txt, TensorVMSplit 128^3, N = 443 (the reference's CPU-runnable case)
+      C2_vm300      TensorVMSplit 300^3, MLP_Fea, N = 1039 (the headline)
+      C3_cp300_*    TensorCP [96] / [288] at 300^3 with the SH head (inference only, as in the reference) / MLP_Fea
+      C4_ndc        forward-facing NDC rays (llff.py:141-143: no white background), VM [16,4,4] / [48,12,12]
+      C5_tt640      Tanks&Temples-like: cameras inside a non-cubic box, near = 0.01, 640^3-equivalent grid
+    `views` Blender views (C1-C3) or `n_rays` generated rays (C4, C5)."""
+    from .field import AlphaGridMask, TensorCP, TensorVMSplit
+    from .utils import N_to_reso, cal_n_samples
+    torch.manual_seed(0)
+    ndc, white = False, True
+    if name in ("C1_vm128", "C2_vm300"):
+        g = 128 if name == "C1_vm128" else 300
+        aabb = torch.tensor(LEGO_AABB, device=device)
+        model = TensorVMSplit(lego_args(), aabb, N_to_reso(g ** 3, aabb), LEGO_NEAR_FAR, device)
+        rays = blender_rays(views)
+    elif name.startswith("C3_cp300"):
+        aabb = torch.tensor(LEGO_AABB, device=device)
+        head = "SH" if name.endswith("sh") else "MLP_Fea"
+        # BASELINE config 3 ([96]/[288], configs/lego.txt:80-83): with the SH head inference only (the reference
+        # cannot train that head either); with MLP_Fea also trained — at 288 components the backward's tile does not
+        # fit LDS in one piece, which exercises its gather-V-twice layout
+        args = lego_args(head, density_n_comp=(96,), app_n_comp=(288,))
+        model = TensorCP(args, aabb, N_to_reso(300 ** 3, aabb), near_far=LEGO_NEAR_FAR, device=device)
+        rays = blender_rays(views)
+    elif name == "C4_ndc":
+        aabb = torch.tensor(LLFF_AABB, device=device)
+        args = lego_args(density_n_comp=(16, 4, 4), app_n_comp=(48, 12, 12))
+        model = TensorVMSplit(args, aabb, N_to_reso(300 ** 3, aabb), LLFF_NEAR_FAR, device)
+        rays, ndc, white = llff_ndc_rays(n_rays or (1 << 16)), True, False
+    elif name == "C5_tt640":
+        aabb = torch.tensor(TT_AABB, device=device)
+        model = TensorVMSplit(lego_args(), aabb, N_to_reso(640 ** 3, aabb), TT_NEAR_FAR, device)
+        rays = tt_rays(n_rays or (1 << 15), TT_AABB)
+    else:
+        raise ValueError(f"unknown scene {name!r}: one of {BASELINE_SCENES}")
+    make_trained_like(model, AlphaGridMask, radius=0.8 if name != "C4_ndc" else 0.9)
+    n_samples = min(int(1e6), cal_n_samples(model.gridSize.tolist(), 0.5))
+    return model, rays, n_samples, ndc, white

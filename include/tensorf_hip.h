@@ -206,9 +206,18 @@ int tf_shade_forward(const TfShade* shade, const float* rays, int ndc, const int
 /* rgb_map = sum w*rgb (+ 1-acc when bg) clamped to [0,1]: tensorBase.py:378-384.  rgb_pre (optional)
  * receives the pre-clamp value, which the backward needs for the clamp mask.  n_shaded (optional, with the sharded
  * counters of the march kernel) receives num_valid_samples = app_mask.sum() (tensorBase.py:390) as one int64. */
+/* `live` (optional): the step's sample counts for the optimizer's gates (TfAdamJob.live) and for the host: dev[0] =
+ * number of density samples (ray_valid.sum(), tensorBase.py:359), dev[1] = number of shaded samples (app_mask.sum(),
+ * :370) as floats in device memory; host[0..1] the same as ints in PINNED host memory (read them after an event
+ * recorded behind this launch: the autograd binding returns None gradients for the tensors the reference's graph would
+ * not contain).  Either pointer may be NULL. */
+typedef struct TfLive {
+    float* dev;
+    int* host;
+} TfLive;
 int tf_composite_forward(int n_rays, const int* app_offset, const int* app_count, const float* app_w,
                          const float* rgb, const float* acc, int white_bg, float* rgb_map, float* rgb_pre,
-                         const int* counters, long long* n_shaded, tf_stream_t stream);
+                         const int* counters, long long* n_shaded, const TfLive* live, tf_stream_t stream);
 /* The same launch followed, inside the kernel, by the photometric loss of train.py:334 and its gradient (what
  * tf_mse_grad computes in a launch of its own): grad[i] = grad_scale * 2 (rgb_map[i] - target[i]) / (3 n_rays), and
  * *loss = mean((rgb_map - target)^2), written once by the last workgroup to finish.  `state` = 2 device words, zero when
@@ -223,7 +232,8 @@ typedef struct TfLossFuse {
 } TfLossFuse;
 int tf_composite_forward_loss(int n_rays, const int* app_offset, const int* app_count, const float* app_w,
                               const float* rgb, const float* acc, int white_bg, float* rgb_map, float* rgb_pre,
-                              const int* counters, long long* n_shaded, const TfLossFuse* fuse, tf_stream_t stream);
+                              const int* counters, long long* n_shaded, const TfLossFuse* fuse, const TfLive* live,
+                              tf_stream_t stream);
 
 /* compute_densityfeature / compute_appfeature on an explicit point list (normalised coordinates),
  * the public hooks used by compute_alpha (tensorBase.py:298-318): out_f (S) / out_feat (S, app_dim). */
@@ -419,11 +429,22 @@ int tf_regularizers(const TfRegJob* job, tf_stream_t stream);
  * storage order: p, g (its gradient, same layout), m / v (first / second moment), n elements, `group` selects
  * the learning rate lrs[group] (train.py uses two: lr_init for the factor tensors, lr_basis for the networks).
  * chunk_end[s] = number of TF_ADAM_CHUNK-element chunks in segments 0..s (one workgroup per chunk).
- * `lrs` and `step` are DEVICE pointers (float).  *step is the number of COMPLETED updates: this launch is update
- * t = *step + 1.  With `arrivals` (one zeroed device uint) the kernel advances the count itself: the last workgroup
- * to finish writes *step_rw = *step + 1 (step_rw == step) and re-arms the counter; with arrivals == NULL the caller
- * advances *step after the launch.  Launches that share `step` must cover all segments in ONE launch (<= 32) to use
- * `arrivals`. */
+ * `lrs` and `step` are DEVICE pointers (float).
+ *
+ * Step counts are PER SEGMENT, like torch.optim.Adam's per-parameter state['step']: step[s] is the number of updates
+ * segment s has COMPLETED, this launch is its update t = step[s] + 1, and the last workgroup to finish advances the
+ * counts of the segments that were updated (`arrivals`: one zeroed device uint per job, re-armed by the kernel).
+ * A segment is NOT updated — moments, parameters and its count stay as they are, exactly what torch.optim.Adam does
+ * with a parameter whose .grad is None — when
+ *   - its bit in `skip_mask` is set (the host knows the parameter has no gradient this step), or
+ *   - it has a gate (`gate & 3`: 1 = live[0], 2 = live[1]) whose device word is zero and none of the regulariser
+ *     flags selected by `gate >> 4` (bit 0 ortho, 1 L1, 2 TV-density, 3 TV-app of reg_active[4]) is non-zero.
+ * Why: in the reference forward the density factors enter the autograd graph only `if ray_valid.any()`
+ * (tensorBase.py:359-364) and the appearance factors, basis matrix and MLP only `if app_mask.any()` (:370-373); in a
+ * step without such samples (the first iterations of a fresh field) their .grad stays None, Adam skips them, and their
+ * bias correction later starts from t = 1.  live[0] / live[1] = number of density / shaded samples of the step
+ * (TfLive, written by tf_composite_forward); the regulariser terms of train.py:340-371 give the factor tensors a
+ * gradient regardless of the samples, hence the flags. */
 #define TF_ADAM_MAX_SEG 32
 #define TF_ADAM_CHUNK 8192
 typedef struct TfAdamSeg {
@@ -433,7 +454,7 @@ typedef struct TfAdamSeg {
     float* v;
     long long n;
     int group;
-    int pad_;
+    int gate;                 /* 0: always updated; else (count index 1 | 2) | (regulariser bits << 4) */
 } TfAdamSeg;
 typedef struct TfAdamJob {
     int n_seg;
@@ -443,13 +464,16 @@ typedef struct TfAdamJob {
     TfAdamSeg seg[TF_ADAM_MAX_SEG];
     int chunk_end[TF_ADAM_MAX_SEG];
     const float* lrs;
-    const float* step;
+    float* step;              /* n_seg device floats: completed updates per segment (read, then advanced) */
     double beta1, beta2, eps;
-    float* step_rw;           /* == step, writable (used with arrivals) */
-    unsigned int* arrivals;   /* NULL, or a zeroed device counter */
+    unsigned int* arrivals;   /* one zeroed device counter per job */
     unsigned int* touched;    /* NULL, or one word per workgroup (chunk of TF_ADAM_CHUNK elements), zero when the
                                * moments are created: bit set = that 256-float piece has had a non-zero gradient;
                                * pieces whose bit is clear have zero moments, which are then not read */
+    const float* live;        /* NULL (no gates), or 2 device floats: density samples, shaded samples of this step */
+    const float* reg_active;  /* NULL, or 4 device floats: non-zero = that regulariser term is part of the loss */
+    unsigned int skip_mask;   /* bit s: segment s has no gradient this step */
+    int pad_;
 } TfAdamJob;
 int tf_adam_step(const TfAdamJob* job, tf_stream_t stream);
 

@@ -1,0 +1,300 @@
+"""PSNR after equal iterations: the HIP path against the eager PyTorch-ROCm oracle on a frozen synthetic teacher
+field (SURVEY §8d "Quality"; the reference computes PSNR at loss.py:46-47 inside train.py:411-445).  TEST INFRASTRUCTURE
+(lives with the oracle it drives): imported by tests/test_psnr_parity.py, tests/psnr_event_diag.py and by bench.py's
+baseline legs; the product package never imports it.
+
+Everything but the arithmetic is identical for the two students: initial parameters, SimpleSampler batch order, the
+CPU-generator jitter stream, Adam groups and learning-rate decay, and — with `schedule=True` — one alpha-mask update
+(tensorBase.py:233-256, no shrink) and one grid up-sampling (tensoRF.py:283-288) with the optimizer rebuilt
+(train.py:450-481), each student rebuilding its own mask / resizing its own tensors.
+
+The two students are objects with one interface (`step`, `mask_event`, `upsample_event`, `params`, `alpha`, `test_psnr`),
+so the same scene can be trained one after the other (`run`) or in lock-step with their states compared, exchanged
+or perturbed at any iteration (tests/psnr_event_diag.py)."""
+import math
+import time
+
+import numpy as np
+import torch
+
+
+def psnr_db(mse):
+    return -10.0 * math.log(max(float(mse), 1e-12)) / math.log(10.0)      # loss.py:46-47
+
+
+class Scene:
+    """Teacher field, its rendered train / test targets (by the HIP path: both students see the same numbers) and the
+    SimpleSampler batch order (train.py:44-56)."""
+
+    def __init__(self, recon, dev="cuda:0", grid=64, iters=400, views=20, res=100, batch=4096, args=None,
+                 teacher_mask_res=64):
+        from recon_amd import synthetic as S
+        self.recon, self.dev, self.grid, self.iters = recon, dev, grid, iters
+        self.args = dict(args or S.lego_args())
+        self.aabb = torch.tensor(S.LEGO_AABB, device=dev)
+        self.near_far = S.LEGO_NEAR_FAR
+        teacher = self.make_model(grid, 123)
+        S.make_trained_like(teacher, recon.AlphaGridMask, mask_res=teacher_mask_res)
+        with torch.no_grad():   # a position-dependent colour
+            teacher.app_plane[0][:, :6] *= 12.0
+            teacher.app_plane[1][:, 6:12] *= 12.0
+            teacher.basis_mat.weight.mul_(3.0)
+        rays_all = S.blender_rays(views + 1, H=res, W=res, seed=7)
+        n_test = res * res
+        self.rays_test, rays_train = rays_all[:n_test].to(dev), rays_all[n_test:].to(dev)
+        with torch.no_grad():
+            gt_train = recon.OctreeRender_trilinear_fast(rays_train, teacher, chunk=batch, white_bg=True, device=dev)[0]
+            self.gt_test = recon.OctreeRender_trilinear_fast(self.rays_test, teacher, chunk=batch, white_bg=True,
+                                                             device=dev)[0]
+        keep = S.bbox_hit_mask(rays_train.cpu(), torch.tensor(S.LEGO_AABB)).to(dev)
+        self.rays_train, self.gt_train = rays_train[keep], gt_train[keep]
+        del teacher
+        self.B = min(batch, self.rays_train.shape[0])
+        self.eval_chunk = batch
+        self.lr_factor = 0.1 ** (1 / iters)
+        rng = np.random.default_rng(11)
+        self.batches, cur, ids = [], self.rays_train.shape[0], None
+        for _ in range(iters):   # SimpleSampler order, shared by both runs
+            cur += self.B
+            if cur + self.B > self.rays_train.shape[0]:
+                ids = torch.from_numpy(rng.permutation(self.rays_train.shape[0])).to(dev)
+                cur = 0
+            self.batches.append(ids[cur:cur + self.B])
+
+    def make_model(self, g, seed):
+        torch.manual_seed(seed)
+        return self.recon.TensorVMSplit(self.args, self.aabb, [g] * 3, self.near_far, self.dev)
+
+    def initial_state(self, g0, seed):
+        m = self.make_model(g0, seed)
+        return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
+class HipStudent:
+    """The product path: recon.TensorVMSplit + renderer + FusedAdam."""
+    name = "hip"
+
+    def __init__(self, scene, g0, init_state):
+        self.sc, recon = scene, scene.recon
+        self.model = scene.make_model(g0, 0)
+        self.model.load_state_dict(init_state)
+        self.model.lazy_sample_count = True
+        self.N = min(int(1e6), recon.cal_n_samples([g0] * 3, 0.5))
+        self.opt = recon.FusedAdam(self.model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+        self.loss = None
+
+    def backward(self, it):
+        sc, recon = self.sc, self.sc.recon
+        ids = sc.batches[it]
+        rgb = recon.OctreeRender_trilinear_fast(sc.rays_train[ids], self.model, None, chunk=sc.B, N_samples=self.N,
+                                                white_bg=True, device=sc.dev, is_train=True)[0]
+        self.loss = torch.mean((rgb - sc.gt_train[ids]) ** 2)
+        self.opt.zero_grad()
+        self.loss.backward()
+
+    def update(self):
+        self.opt.step()
+        for g in self.opt.param_groups:
+            g["lr"] *= self.sc.lr_factor
+
+    def step(self, it):
+        self.backward(it)
+        self.update()
+
+    def grads(self):
+        return {k: p.grad.detach().contiguous() for k, p in self.model.named_parameters()}
+
+    def load_moments(self, mom):
+        for k, p in self.model.named_parameters():
+            if p in self.opt.state and k in mom:
+                self.opt.state[p]["exp_avg"].copy_(mom[k][0])
+                self.opt.state[p]["exp_avg_sq"].copy_(mom[k][1])
+
+    def mask_event(self, reso):
+        return self.model.updateAlphaMask(tuple(reso))
+
+    def upsample_event(self, grid, it):
+        sc, recon = self.sc, self.sc.recon
+        self.model.upsample_volume_grid([grid] * 3)
+        self.N = min(self.N, recon.cal_n_samples([grid] * 3, 0.5))           # train.py:472
+        self.opt = recon.FusedAdam(self.model.get_optparam_groups(0.02 * sc.lr_factor ** (it + 1),
+                                                                  1e-3 * sc.lr_factor ** (it + 1)), betas=(0.9, 0.99))
+
+    def params(self):
+        return {k: v.detach().contiguous() for k, v in self.model.state_dict().items()
+                if not k.startswith("alphaMask")}
+
+    def load_params(self, state):
+        with torch.no_grad():
+            for k, p in self.model.named_parameters():
+                p.copy_(state[k])
+        torch.autograd.graph.increment_version(list(self.model.parameters()))
+
+    def alpha(self):
+        am = self.model.alphaMask
+        return None if am is None else am.alpha_volume[0, 0] > 0.5
+
+    def set_alpha(self, vol_bool):
+        self.model.alphaMask = self.sc.recon.AlphaGridMask(self.sc.dev, self.model.aabb, vol_bool.float())
+
+    def moments(self):
+        return {k: (self.opt.state[p]["exp_avg"].detach().contiguous(), self.opt.state[p]["exp_avg_sq"].detach().contiguous())
+                for k, p in self.model.named_parameters() if p in self.opt.state}
+
+    def step_size(self):
+        return float(self.model.stepSize)
+
+    def test_psnr(self):
+        sc = self.sc
+        with torch.no_grad():
+            out = sc.recon.OctreeRender_trilinear_fast(sc.rays_test, self.model, chunk=sc.eval_chunk, N_samples=self.N,
+                                                       white_bg=True, device=sc.dev)[0]
+        return psnr_db(torch.mean((out.clamp(0, 1) - sc.gt_test) ** 2))
+
+    def finish(self):
+        self.model.check_scatter_status()
+
+
+class EagerStudent:
+    """The oracle (the reference's arithmetic in eager PyTorch on the same GPU) + torch.optim.Adam."""
+    name = "eager"
+
+    def __init__(self, scene, g0, init_state):
+        from oracle import ref_torch as R
+        self.sc, self.R = scene, R
+        a = scene.args
+        self.cfg = R.FieldCfg(model="TensorVMSplit", aabb=scene.aabb.clone(), gridSize=[g0] * 3, near_far=scene.near_far,
+                              **{k: v for k, v in a.items() if k not in ("alphaMask_thres",)}).finalize()
+        self.thres = a["alphaMask_thres"]
+        self.p = {k: v.detach().contiguous().clone().requires_grad_(True) for k, v in init_state.items()}
+        self.N = min(int(1e6), R.cal_n_samples([g0] * 3, 0.5))
+        self.opt = self._make_opt(0.02, 1e-3)
+        self.loss = None
+
+    def _make_opt(self, lr_xyz, lr_net):
+        fast = [v for k, v in self.p.items() if "_plane." in k or "_line." in k]
+        slow = [v for k, v in self.p.items() if not ("_plane." in k or "_line." in k)]
+        return torch.optim.Adam([{"params": fast, "lr": lr_xyz}, {"params": slow, "lr": lr_net}], betas=(0.9, 0.99))
+
+    def backward(self, it):
+        sc = self.sc
+        ids = sc.batches[it]
+        rgb, _, _ = self.R.render_rays(self.cfg, self.p, sc.rays_train[ids], None, white_bg=True, is_train=True,
+                                       n_samples=self.N)
+        self.loss = torch.mean((rgb - sc.gt_train[ids]) ** 2)
+        self.opt.zero_grad()
+        self.loss.backward()
+
+    def update(self):
+        self.opt.step()
+        for g in self.opt.param_groups:
+            g["lr"] *= self.sc.lr_factor
+
+    def step(self, it):
+        self.backward(it)
+        self.update()
+
+    def grads(self):
+        return {k: (v.grad.detach() if v.grad is not None else torch.zeros_like(v)) for k, v in self.p.items()}
+
+    def load_moments(self, mom):
+        for k, v in self.p.items():
+            if v in self.opt.state and k in mom:
+                self.opt.state[v]["exp_avg"].copy_(mom[k][0])
+                self.opt.state[v]["exp_avg_sq"].copy_(mom[k][1])
+
+    def mask_event(self, reso):
+        return self.R.update_alpha_mask(self.cfg, self.p, tuple(reso), self.thres)
+
+    def upsample_event(self, grid, it):
+        sc = self.sc
+        self.p = self.R.upsample_params(self.cfg, self.p, [grid] * 3)
+        self.N = min(self.N, self.R.cal_n_samples([grid] * 3, 0.5))
+        self.opt = self._make_opt(0.02 * sc.lr_factor ** (it + 1), 1e-3 * sc.lr_factor ** (it + 1))
+
+    def params(self):
+        return {k: v.detach() for k, v in self.p.items()}
+
+    def load_params(self, state):
+        with torch.no_grad():
+            for k, v in self.p.items():
+                v.copy_(state[k])
+
+    def alpha(self):
+        return None if self.cfg.alpha_volume is None else self.cfg.alpha_volume > 0.5
+
+    def set_alpha(self, vol_bool):
+        self.cfg.alpha_volume, self.cfg.alpha_aabb = vol_bool.float(), self.cfg.aabb.clone()
+
+    def moments(self):
+        return {k: (self.opt.state[v]["exp_avg"], self.opt.state[v]["exp_avg_sq"]) for k, v in self.p.items()
+                if v in self.opt.state}
+
+    def step_size(self):
+        return float(self.cfg.stepSize)
+
+    def test_psnr(self):
+        sc = self.sc
+        with torch.no_grad():
+            out = self.R.render_chunked(self.cfg, self.p, sc.rays_test, None, chunk=sc.eval_chunk, n_samples=self.N,
+                                        white_bg=True, device=sc.dev)[0]
+        return psnr_db(torch.mean((out.clamp(0, 1) - sc.gt_test) ** 2))
+
+    def finish(self):
+        pass
+
+
+def train_alone(student, scene, schedule, mask_at, upsample_at, mask_reso, cuts=()):
+    """One student through all iterations (its own CPU-generator jitter stream, seeded here).  Returns (seconds,
+    {cut iteration: test PSNR})."""
+    torch.manual_seed(99)
+    torch.cuda.synchronize()
+    at_cut, spent = {}, 0.0
+    t0 = time.perf_counter()
+    for it in range(scene.iters):
+        student.step(it)
+        if schedule and it == mask_at:
+            student.mask_event(mask_reso)
+        if schedule and it == upsample_at:
+            student.upsample_event(scene.grid, it)
+        if (it + 1) in cuts and (it + 1) != scene.iters:      # evaluation draws nothing from the jitter stream
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            at_cut[it + 1] = student.test_psnr()
+            torch.cuda.synchronize()
+            spent += time.perf_counter() - t1
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0 - spent, at_cut
+
+
+def run(recon, dev="cuda:0", grid=64, iters=400, views=20, res=100, batch=4096, schedule=False, seed=5,
+        init_grid=None, mask_at=None, upsample_at=None, cuts=(), args=None, teacher_mask_res=64, eager=True):
+    """Trains the HIP student, then (eager=True) the oracle student, on the same scene; `cuts`: iterations after
+    which both are also evaluated (the delta is reported at every cut, not at one chosen length)."""
+    scene = Scene(recon, dev, grid, iters, views, res, batch, args=args, teacher_mask_res=teacher_mask_res)
+    g0 = init_grid if (schedule and init_grid) else grid
+    mask_at = (iters * 3 // 8) if mask_at is None else mask_at
+    upsample_at = (iters * 5 // 8) if upsample_at is None else upsample_at
+    mask_reso = (64, 64, 64)
+    init_state = scene.initial_state(g0, seed)
+
+    hip = HipStudent(scene, g0, init_state)
+    t_hip, cut_hip = train_alone(hip, scene, schedule, mask_at, upsample_at, mask_reso, cuts)
+    psnr_hip = hip.test_psnr()
+    hip.finish()
+    out = {"grid": grid, "init_grid": g0, "iters": iters, "batch": scene.B, "train_rays": int(scene.rays_train.shape[0]),
+           "seed": seed,
+           "schedule": ({"alpha_mask_update_at": mask_at, "upsample_at": upsample_at, "mask_reso": list(mask_reso)}
+                        if schedule else None),
+           "psnr_hip_db": psnr_hip, "train_seconds_hip": t_hip, "final_train_loss_hip": float(hip.loss.detach()),
+           "data": "synthetic teacher only (no dataset exists offline): targets rendered from a frozen seeded field"}
+    if not eager:
+        return out
+    ora = EagerStudent(scene, g0, init_state)
+    t_eager, cut_eager = train_alone(ora, scene, schedule, mask_at, upsample_at, mask_reso, cuts)
+    psnr_eager = ora.test_psnr()
+    out.update({"psnr_eager_db": psnr_eager, "delta_db": psnr_hip - psnr_eager, "train_seconds_eager": t_eager,
+                "final_train_loss_eager": float(ora.loss.detach()),
+                "cuts": {str(c): {"hip": cut_hip[c], "eager": cut_eager[c], "delta_db": cut_hip[c] - cut_eager[c]}
+                         for c in sorted(cut_hip)}})
+    return out

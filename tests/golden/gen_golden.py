@@ -419,9 +419,54 @@ def aux_refs():
     print("aux_refs done:", sorted(k for k in rec if k.endswith("loss")), {k: rec[k].shape for k in rec if k.endswith("rays_d")})
 
 
+def adam_trajectory():
+    """11: what `optimizer.step()` does in the first iterations of a fresh field (train.py:272-273, 374-376): while no
+    sample passes `weight > rayMarch_weight_thres`, `app_mask.any()` is False (tensorBase.py:370), the appearance factors,
+    the basis matrix and the MLP are not part of the autograd graph, their .grad stays None and torch.optim.Adam skips
+    them — no moment decay and no step count, so their bias correction starts at t = 1 when the first shaded sample
+    arrives.  Recorded per step: loss, num_valid_samples, which parameters had no gradient; at the end: parameters and
+    Adam's per-parameter step counts."""
+    cube = torch.tensor([[-1.5, -1.5, -1.5], [1.5, 1.5, 1.5]])
+    torch.manual_seed(21)
+    m = quiet(TensorVMSplit, base_args(density_n_comp=[8, 8, 8], app_n_comp=[8, 8, 8], featureC=64), cube, [24, 24, 24],
+              [2.0, 6.0], "cpu")
+    names = [k for k, _ in m.named_parameters()]
+    rec = {"state0/" + k: v.numpy().copy() for k, v in m.state_dict().items()}
+    rays = outside_rays(192, 31)
+    g = torch.Generator().manual_seed(32)
+    target = torch.rand(192, 3, generator=g) * 0.5
+    steps = 16
+    opt = torch.optim.Adam(m.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+    none = np.zeros((steps, len(names)), dtype=np.uint8)
+    losses, shaded = [], []
+    for it in range(steps):
+        torch.manual_seed(1000 + it)                      # the jitter draw of tensorBase.py:201
+        rgb, _, nv = m(rays, None, white_bg=True, is_train=True)
+        loss = torch.mean((rgb - target) ** 2)
+        opt.zero_grad()
+        loss.backward()
+        for j, (k, p) in enumerate(m.named_parameters()):
+            none[it, j] = p.grad is None
+        opt.step()
+        losses.append(loss.item())
+        shaded.append(int(nv))
+    rec["names"] = np.array(names)
+    rec["rays"], rec["target"] = rays.numpy(), target.numpy()
+    rec["loss"], rec["num_valid"], rec["grad_is_none"] = np.float32(losses), np.int64(shaded), none
+    for k, p in m.named_parameters():
+        rec["final/" + k] = p.detach().numpy().copy()
+        rec["adam_step/" + k] = np.float32(float(opt.state[p]["step"]) if p in opt.state and "step" in opt.state[p] else 0.0)
+    np.savez_compressed(os.path.join(OUT, "adam_trajectory.npz"), **rec)
+    print("adam_trajectory done: shaded per step", shaded, "steps without appearance gradient",
+          int(none[:, names.index("basis_mat.weight")].sum()))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "aux":
         aux_refs()
+    elif len(sys.argv) > 1 and sys.argv[1] == "adam":
+        adam_trajectory()
     else:
         main()
         aux_refs()
+        adam_trajectory()

@@ -34,7 +34,7 @@ def test_ctypes_structs_match_header_field_order(recon):
     """Field names of the ctypes mirrors appear in the header's struct bodies in the same order."""
     text = open(os.path.join(ROOT, "include", "tensorf_hip.h")).read()
     for cname in ("TfFactors", "TfFactorGrads", "TfField", "TfMarchIO", "TfPeBlock", "TfShade", "TfShadeGrads", "TfShadeSave",
-                  "TfAdamSeg", "TfAdamJob", "TfRegJob", "TfPackItem", "TfPackJob", "TfCamera"):
+                  "TfAdamSeg", "TfAdamJob", "TfRegJob", "TfPackItem", "TfPackJob", "TfCamera", "TfLive"):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), text, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         decl = []

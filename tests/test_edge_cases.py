@@ -69,9 +69,14 @@ def test_sample_count_limit(recon):
         model(rays, None, white_bg=True, is_train=False, N_samples=8193)
 
 
-def test_training_step_without_shaded_samples(recon):
-    """A batch whose rays all miss: forward, backward and both optimizers run, every gradient is exactly zero."""
+@pytest.mark.parametrize("none_grads", [True, False])
+def test_training_step_without_shaded_samples(recon, none_grads):
+    """A batch whose rays all miss: forward, backward and the optimizer run and nothing changes.  With
+    `reference_none_grads` (default) no parameter gets a gradient — the reference's graph holds none of them without a
+    valid sample (tensorBase.py:359, :370; its own backward() would even refuse the loss) — without it every gradient
+    is a tensor of exact zeros and FusedAdam's device-side gates keep the step counts where they are."""
     c, model = _model(recon, "vm_cubic_train")
+    model.reference_none_grads = none_grads
     o = torch.tensor([[5.0, 5.0, 5.0]], device=DEV).repeat(256, 1)
     d = torch.nn.functional.normalize(torch.tensor([[1.0, 0.3, 0.2]], device=DEV), dim=-1).repeat(256, 1)
     rays = torch.cat([o, d], 1)
@@ -82,10 +87,15 @@ def test_training_step_without_shaded_samples(recon):
     opt.zero_grad()
     loss.backward()
     for k, p in model.named_parameters():
-        assert p.grad is not None and float(p.grad.abs().max()) == 0.0, k
+        if none_grads:
+            assert p.grad is None, k
+        else:
+            assert p.grad is not None and float(p.grad.abs().max()) == 0.0, k
     opt.step()
     for k, v in model.state_dict().items():
         assert torch.equal(v, before[k]), k
+    if not none_grads:
+        assert all(float(opt.state[p]["step"]) == 0.0 for p in model.parameters())
 
 
 def test_generated_rays_match_the_loader_formulas(recon):

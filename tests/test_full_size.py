@@ -25,38 +25,12 @@ from tests.test_hip_forward import ATOL_RGB, RTOL, bits_to_mask
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-TT_AABB = [[-2.4, -1.6, -1.9], [2.2, 1.7, 1.3]]
 
 
 def _scene(recon, name):
+    """One 4096-ray batch of a BASELINE configuration (recon_amd.synthetic.baseline_scene: what bench.py --config runs)."""
     from recon_amd import synthetic as S
-    torch.manual_seed(0)
-    ndc, white = False, True
-    if name in ("C1_vm128", "C2_vm300"):
-        g = 128 if name == "C1_vm128" else 300
-        aabb = torch.tensor(S.LEGO_AABB, device=DEV)
-        model = recon.TensorVMSplit(S.lego_args(), aabb, recon.N_to_reso(g ** 3, aabb), S.LEGO_NEAR_FAR, DEV)
-        rays = S.blender_rays(1)
-    elif name.startswith("C3_cp300"):
-        aabb = torch.tensor(S.LEGO_AABB, device=DEV)
-        head = "SH" if name.endswith("sh") else "MLP_Fea"
-        # BASELINE config 3 ([96]/[288], configs/lego.txt:80-83): with the SH head inference only (the reference
-        # cannot train that head either); with MLP_Fea also trained — at 288 components the backward's tile does not
-        # fit LDS in one piece, which exercises its gather-V-twice layout
-        args = S.lego_args(head, density_n_comp=(96,), app_n_comp=(288,))
-        model = recon.TensorCP(args, aabb, recon.N_to_reso(300 ** 3, aabb), near_far=S.LEGO_NEAR_FAR, device=DEV)
-        rays = S.blender_rays(1)
-    elif name == "C4_ndc":
-        aabb = torch.tensor(S.LLFF_AABB, device=DEV)
-        args = S.lego_args(density_n_comp=(16, 4, 4), app_n_comp=(48, 12, 12))
-        model = recon.TensorVMSplit(args, aabb, recon.N_to_reso(300 ** 3, aabb), S.LLFF_NEAR_FAR, DEV)
-        rays, ndc, white = S.llff_ndc_rays(1 << 16), True, False
-    else:   # C5_tt640
-        aabb = torch.tensor(TT_AABB, device=DEV)
-        model = recon.TensorVMSplit(S.lego_args(), aabb, recon.N_to_reso(640 ** 3, aabb), S.TT_NEAR_FAR, DEV)
-        rays = S.tt_rays(1 << 15, TT_AABB)
-    S.make_trained_like(model, recon.AlphaGridMask, radius=0.8 if name != "C4_ndc" else 0.9)
-    n_samples = min(int(1e6), recon.cal_n_samples(model.gridSize.tolist(), 0.5))
+    model, rays, n_samples, ndc, white = S.baseline_scene(name, DEV)
     perm = torch.randperm(rays.shape[0], generator=torch.Generator().manual_seed(1))[:4096]
     return model, rays[perm].to(DEV).contiguous(), n_samples, ndc, white
 
