@@ -136,20 +136,52 @@ class _MLPBase(nn.Module):
         owner = self._owner() if self._owner is not None else None
         if owner is None:
             raise H.HipError("this shading head is not attached to a field model (TensorBase.init_render_func)")
-        dev = features.device
-        if not features.is_cuda:
-            raise H.HipError("renderModule needs its inputs on the GPU (no CPU path in this build)")
-        if owner._geom is None:
-            owner._field_desc([None, None, None])
-        shade, keep = owner._shade_desc([None, None, None], mask, dev)
-        n = features.shape[0]
-        f = features.detach().reshape(n, -1).to(torch.float32).contiguous()
-        p = pts.detach().reshape(n, 3).to(torch.float32).contiguous()
-        v = viewdirs.detach().reshape(n, 3).to(torch.float32).contiguous()
-        out = torch.empty(n, 3, dtype=torch.float32, device=dev)
-        H.check(H.lib().tf_shade_points(C.byref(shade), p.data_ptr(), v.data_ptr(), f.data_ptr(), n, out.data_ptr(),
-                                        _stream()), "tf_shade_points")
-        return out
+        return _shade_points(owner, pts, viewdirs, features, mask)
+
+
+def _shade_points(owner, pts, viewdirs, features, mask):
+    """tf_shade_points on explicit (pts, viewdirs, features) lists with the head `owner` is configured for."""
+    dev = features.device
+    if not features.is_cuda:
+        raise H.HipError("renderModule needs its inputs on the GPU (no CPU path in this build)")
+    if owner._geom is None:
+        owner._field_desc([None, None, None])
+    shade, keep = owner._shade_desc([None, None, None], mask, dev)
+    n = features.shape[0]
+    f = features.detach().reshape(n, -1).to(torch.float32).contiguous()
+    p = pts.detach().reshape(n, 3).to(torch.float32).contiguous()
+    v = viewdirs.detach().reshape(n, 3).to(torch.float32).contiguous()
+    out = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    H.check(H.lib().tf_shade_points(C.byref(shade), p.data_ptr(), v.data_ptr(), f.data_ptr(), n, out.data_ptr(),
+                                    _stream()), "tf_shade_points")
+    return out
+
+
+class _FixedHead:
+    """The parameter-free heads as callables with the reference's signature — `SHRender(xyz_sampled, viewdirs, features)`
+    (models/mlp.py:15-21: relu(sum(sh_basis(viewdirs) * features.view(-1, 3, 9)) + 0.5)) and `RGBRender` (:24-25: the
+    first three features) — on the same kernel that shades inside TensorBase.forward.  Compares equal to its name, so
+    `model.renderModule == 'SH'` keeps working."""
+
+    def __init__(self, owner, name):
+        import weakref
+        self._owner, self.name = weakref.ref(owner), name
+
+    def __call__(self, xyz_sampled, viewdirs, features, mask=None):
+        owner = self._owner()
+        if owner is None:
+            raise H.HipError("this shading head's field model is gone")
+        with torch.no_grad():
+            return _shade_points(owner, xyz_sampled, viewdirs, features, None)
+
+    def __eq__(self, other):
+        return other == self.name if isinstance(other, str) else other is self
+
+    def __hash__(self):
+        return hash(self.name)
+
+    def __repr__(self):
+        return f"{self.name}Render"
 
 
 class MLPRender_Fea(_MLPBase):
@@ -317,7 +349,7 @@ class TensorBase(nn.Module):
         elif shadingMode == 'MLP':
             self.renderModule = MLPRender(self.app_dim, view_pe, pos_pe, fea_pe, featureC).to(device)
         elif shadingMode in ('SH', 'RGB'):
-            self.renderModule = shadingMode
+            self.renderModule = _FixedHead(self, shadingMode)
         else:
             raise ValueError(f"Unrecognized shading module {shadingMode!r}")
         if isinstance(self.renderModule, nn.Module):

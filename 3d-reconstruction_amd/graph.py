@@ -19,7 +19,8 @@ caller then assigns the rebuilt optimizer to `.opt`, as train.py:300-311 rebuild
 runs one eager step and captures again.
 
 Restrictions (else use the eager path): fixed batch size / N_samples.  With `white_bg=False` the random background
-draw of tensorBase.py:380 stays a host decision per step: the step is captured once per outcome (single process only).  Results of EARLIER eager training forwards of the same
+draw of tensorBase.py:380 stays a host decision per step: the step is captured once per outcome (data parallel: one
+draw per global batch, shared by the ranks — see `bg_seed`).  Results of EARLIER eager training forwards of the same
 model (`rgb`, the loss) must not be alive when the step is captured: they keep autograd's AccumulateGrad nodes bound
 to the stream they ran on, the capture would record a dependency on that stream and HIP fails in
 `hipStreamEndCapture` (torch warns "AccumulateGrad node's stream does not match")."""
@@ -40,7 +41,7 @@ class GraphedTrainStep:
     EARLY_SORT_LIMITS = (500_000, 170_000)
 
     def __init__(self, model, optimizer, batch, n_samples, mask=None, ndc_ray=False, warmup=3, split=None,
-                 early_sort='auto', white_bg=True, regularizers=False):
+                 early_sort='auto', white_bg=True, regularizers=False, bg_seed=20211202):
         self.model, self.opt = model, optimizer
         # split: capture backward and optimizer separately with the gradient all-reduce in between
         self.split = (dist.is_available() and dist.is_initialized() and
@@ -65,14 +66,19 @@ class GraphedTrainStep:
         self._packjobs = {}                                # use_bg -> the captured forward's TfPackJob (run by _stage)
         self._dist = dist.is_available() and dist.is_initialized()
         self._items, self._items_d, self._items_r = {}, [], []      # data parallel: the buckets' (buffer, rows, width) pieces
-        self.n_samples, self.mask, self.ndc = n_samples, mask, ndc_ray
+        self.n_samples, self.ndc = n_samples, ndc_ray
+        # FreeNeRF masks (train.py:303-318: a new mask dict every iteration with `free_reg`): the step keeps every mask
+        # vector in ONE static device buffer the captured kernels read; set_mask() refreshes its values before a replay
+        self.mask, self._mask_buf, self._mask_sig = None, None, None
         # white_bg=False (datasets without a white background, e.g. llff.py:141): the reference adds the white
         # background to a training batch with probability 1/2 (tensorBase.py:380) — a host decision per step, so the
         # step is captured once per outcome and the draw (same generator, same position in the stream) picks the graph
         self.white_bg = bool(white_bg)
-        if self.split and not self.white_bg:
-            raise NotImplementedError("GraphedTrainStep: random backgrounds (white_bg=False) are not combined with the "
-                                      "data-parallel split step yet; use the eager loop")
+        # ... data parallel: the reference has one process and one draw per batch.  Rule chosen here: one draw per GLOBAL
+        # batch — every rank reads it from a generator all ranks seed alike (`bg_seed`), so the ranks replay the same
+        # variant and their shards together are the batch a single process would have rendered; each rank still takes
+        # the reference's draw from its default generator (discarded), which keeps that stream where train.py's loop has it
+        self._bg_gen = torch.Generator().manual_seed(int(bg_seed)) if (self.split and not self.white_bg) else None
         self._graphs = {}            # use_bg -> (graph, graph_opt)
         # regularizers=True: tf_regularizers (train.py:340-371 in one pass) runs between the backward and the optimizer
         # with its four weights read from device memory — set_regularizer_weights() before each step follows the
@@ -85,6 +91,8 @@ class GraphedTrainStep:
         # PyTorch's whole-network capture recipe: warm-up iterations and the capture run on the same side
         # stream, so the autograd AccumulateGrad nodes are bound to the stream that is later captured
         self._side = torch.cuda.Stream(device=dev)
+        if mask is not None:
+            self.set_mask(mask)
 
     def _signature(self):
         """What a captured graph depends on besides the static buffers: the alpha mask object and the parameters'
@@ -126,6 +134,64 @@ class GraphedTrainStep:
         f.target, f.grad_scale = self.target.data_ptr(), float(grad_scale)
         f.grad, f.loss, f.state = self._grad_rgb.data_ptr(), self.loss.data_ptr(), self._loss_state.data_ptr()
         return f
+
+    def _mask_rows(self, mask):
+        """[(group, key, plane index | None, length, value)] for every mask vector of `mask`, in a fixed order; the value is
+        whatever the reference indexes (`mask['decomp']['den'][i]`: a scalar or a (C_i,) vector; an encoding mask: a
+        scalar or a vector over the encoding's columns) — broadcast to `length` when it is uploaded."""
+        m = self.model
+        cp = m._is_cp()
+        rows = []
+        for key, comps in (("den", m.density_n_comp), ("app", m.app_n_comp)):
+            v = mask["decomp"][key]
+            if v is not None:
+                for i in range(1 if cp else 3):
+                    rows.append(("decomp", key, i, int(comps[0] if cp else comps[i]), v[i]))
+        enc_len = {"pos": 2 * 3 * m.pos_pe, "view": 2 * 3 * m.view_pe, "fea": 2 * m.app_dim * m.fea_pe}
+        for key in ("pos", "view", "fea"):
+            v = mask["encoding"].get(key)
+            if v is not None:
+                rows.append(("encoding", key, None, enc_len[key], v))
+        return rows
+
+    def set_mask(self, mask):
+        """The FreeNeRF mask dict of the next step(s) (utils.get_free_mask, train.py:303-318), or None.  The values go
+        into the step's static mask buffer (one small H2D copy from a fresh pinned tensor, ordered before the next
+        replay); only a change of the dict's STRUCTURE (which entries are None) makes the step capture again."""
+        if mask is None:
+            if self.mask is not None:
+                self.mask, self._mask_buf, self._mask_sig = None, None, None
+                self._graphs, self._packjobs, self._items = {}, {}, {}
+                self.graph = self.graph_opt = None
+                self._warm = max(self._warm, 1)
+            return
+        rows = self._mask_rows(mask)
+        sig = tuple(r[:4] for r in rows)
+        dev = self.rays.device
+        if sig != self._mask_sig:
+            total = sum(r[3] for r in rows)
+            self._mask_buf = torch.ones(max(total, 1), device=dev)
+            static = {"encoding": {"pos": None, "view": None, "fea": None}, "decomp": {"den": None, "app": None}}
+            off = 0
+            for grp, key, i, n, _ in rows:
+                view = self._mask_buf[off:off + n]
+                off += n
+                if grp == "decomp":
+                    if static[grp][key] is None:
+                        static[grp][key] = []
+                    static[grp][key].append(view)
+                else:
+                    static[grp][key] = view
+            had = self._mask_sig is not None or bool(self._graphs)
+            self.mask, self._mask_sig = static, sig
+            if had:     # other mask pointers than the captured ones: capture again
+                self._graphs, self._packjobs, self._items = {}, {}, {}
+                self.graph = self.graph_opt = None
+                self._warm = max(self._warm, 1)
+        if rows:
+            host = torch.cat([torch.broadcast_to(torch.as_tensor(v, dtype=torch.float32).detach().cpu().reshape(-1), (n,))
+                              for _, _, _, n, v in rows])
+            self._mask_buf.copy_(host.pin_memory(), non_blocking=True)
 
     def set_regularizer_weights(self, ortho=0.0, l1=0.0, tv_density=0.0, tv_app=0.0):
         """Weights of the four regulariser terms for the next step(s) (needs regularizers=True)."""
@@ -277,6 +343,8 @@ class GraphedTrainStep:
         slot = self._draw_jitter()
         # random-background draw of tensorBase.py:380, taken after the jitter draw like the reference's forward does
         self._bg = True if self.white_bg else bool(torch.rand((1,)) < 0.5)
+        if self._bg_gen is not None:
+            self._bg = bool(torch.rand((1,), generator=self._bg_gen) < 0.5)
         self._stage(rays, target, ids, slot)
         self.model._bg_override = self._bg
         try:

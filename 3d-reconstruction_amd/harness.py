@@ -61,7 +61,8 @@ def train(tensorf, allrays, allrgbs, cfg=None, device="cuda", rank=0, world=1, l
 
     graphed=True drives every iteration through `GraphedTrainStep` (forward, MSE, backward, regularisers, Adam replayed
     from a hipGraph; re-captured after each schedule event): same schedule, same host RNG stream, the rays are kept on
-    the GPU.  Not with `free_reg` (the FreeNeRF masks change every iteration)."""
+    the GPU; with `free_reg` the iteration's FreeNeRF masks are uploaded into the step's static mask buffer
+    (GraphedTrainStep.set_mask)."""
     c = dict(DEFAULTS)
     c.update(cfg or {})
     aabb = tensorf.aabb
@@ -90,8 +91,8 @@ def train(tensorf, allrays, allrgbs, cfg=None, device="cuda", rank=0, world=1, l
     gs = None
     if graphed:
         from .graph import GraphedTrainStep
-        if c["free_reg"] or not fused_supported(tensorf) or c.get("optimizer", "fused") == "torch":
-            raise ValueError("harness.train(graphed=True) needs the fused regularisers / FusedAdam and no free_reg masks")
+        if not fused_supported(tensorf) or c.get("optimizer", "fused") == "torch":
+            raise ValueError("harness.train(graphed=True) needs the fused regularisers / FusedAdam")
         allrays, allrgbs = allrays.to(device).float().contiguous(), allrgbs.to(device).float().contiguous()
         gs = GraphedTrainStep(tensorf, opt, batch, nSamples, ndc_ray=c["ndc_ray"], white_bg=c["white_bg"], warmup=1,
                               regularizers=True)
@@ -109,16 +110,19 @@ def train(tensorf, allrays, allrgbs, cfg=None, device="cuda", rank=0, world=1, l
         if tv_a > 0:
             tv_a *= lr_factor
         use_ortho = ortho_w if hasattr(tensorf, "vector_comp_diffs") else 0.0
+        if c["free_reg"]:
+            mask = get_free_mask(pos_bl=tensorf.pos_bit_length, view_bl=tensorf.view_bit_length,
+                                 fea_bl=tensorf.fea_bit_length, den_bl=tensorf.density_n_comp,
+                                 app_bl=tensorf.app_n_comp, step=it, total_step=n_iters,
+                                 device="cpu" if gs is not None else device)           # train.py:303-318
         if gs is not None:       # the iteration below, replayed from a hipGraph (re-captured after schedule events)
             gs.opt, gs.n_samples = opt, nSamples
+            if mask is not None:
+                gs.set_mask(mask)
             gs.set_regularizer_weights(use_ortho, l1_w, max(tv_d, 0.0), max(tv_a, 0.0))
             loss = gs.step(allrays, allrgbs, ids)
         else:
             rays_train, rgb_train = allrays[ids], allrgbs[ids].to(device)
-            if c["free_reg"]:
-                mask = get_free_mask(pos_bl=tensorf.pos_bit_length, view_bl=tensorf.view_bit_length,
-                                     fea_bl=tensorf.fea_bit_length, den_bl=tensorf.density_n_comp,
-                                     app_bl=tensorf.app_n_comp, step=it, total_step=n_iters, device=device)   # train.py:303-318
             rgb_map, _, depth_map, _, _, n = OctreeRender_trilinear_fast(
                 rays_train, tensorf, mask, chunk=batch, N_samples=nSamples, white_bg=c["white_bg"], ndc_ray=c["ndc_ray"],
                 device=device, is_train=True)

@@ -461,8 +461,49 @@ def adam_trajectory():
           int(none[:, names.index("basis_mat.weight")].sum()))
 
 
+def full_size_c1():
+    """12: one full-size output vector from the reference itself ("one full-size smoke hash at C1"):
+    BASELINE config 1 — TensorVMSplit 128^3, [16,16,16]/[48,48,48], MLP_Fea, N = 443 — on 4096 synthetic Blender rays,
+    eval forward.  The 3 M parameters are not stored: the model is the seed-0 initialisation (the product reproduces
+    the reference's init draw for draw, tests/test_abi_and_host.py) + the 'trained-like' edit + a 128^3 ball mask, all
+    restated below exactly as recon_amd.synthetic builds them; a digest of the state guards that assumption."""
+    import math
+    cube = torch.tensor([[-1.5, -1.5, -1.5], [1.5, 1.5, 1.5]])
+    torch.manual_seed(0)
+    m = quiet(TensorVMSplit, base_args(), cube, [128, 128, 128], [2.0, 6.0], "cpu")
+    trained_like_vm(m, ball_res=(128, 128, 128), radius=0.8)
+    # rays: synthetic.blender_rays(1) restated (one camera on the upper hemisphere, unit directions), 4096 of them
+    rng = np.random.default_rng(20211202)
+    H = W = 800
+    focal = 0.5 * W / math.tan(0.5 * 0.6911112070083618)
+    j, i = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    dirs = torch.stack([(i + 0.5 - W / 2) / focal, (j + 0.5 - H / 2) / focal, torch.ones_like(i)], -1)
+    dirs = dirs / torch.norm(dirs, dim=-1, keepdim=True)
+    th = rng.uniform(0, 2 * math.pi)
+    ph = rng.uniform(math.radians(10), math.radians(80))
+    cam = np.array([math.cos(th) * math.cos(ph), math.sin(th) * math.cos(ph), math.sin(ph)]) * 4.0311
+    fwd = -cam / np.linalg.norm(cam)
+    right = np.cross(fwd, np.array([0.0, 0.0, 1.0]))
+    right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    c2w = torch.tensor(np.stack([right, down, fwd, cam], axis=1), dtype=torch.float32)
+    d = dirs.view(-1, 3) @ c2w[:, :3].T
+    rays = torch.cat([c2w[:, 3].expand_as(d), d], 1)
+    perm = torch.randperm(rays.shape[0], generator=torch.Generator().manual_seed(1))[:4096]
+    rays = rays[perm].contiguous()
+    with torch.no_grad():
+        rgb, depth, nv = m(rays, None, white_bg=True, is_train=False, ndc_ray=False, N_samples=443)
+    digest = np.float64(sum(float(v.double().sum()) for k, v in m.state_dict().items() if not k.startswith("alphaMask")))
+    np.savez_compressed(os.path.join(OUT, "full_size_c1.npz"), rays=rays.numpy(), rgb_map=rgb.numpy(), depth_map=depth.numpy(),
+                        num_valid=np.int64(nv.item()), state_digest=digest, n_samples=np.int64(443),
+                        alpha_kept=np.int64(m.alphaMask.alpha_volume.sum().item()))
+    print("full_size_c1 done: shaded", int(nv), "digest", float(digest), "rgb mean", float(rgb.mean()))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "aux":
+    if len(sys.argv) > 1 and sys.argv[1] == "c1":
+        full_size_c1()
+    elif len(sys.argv) > 1 and sys.argv[1] == "aux":
         aux_refs()
     elif len(sys.argv) > 1 and sys.argv[1] == "adam":
         adam_trajectory()
@@ -470,3 +511,4 @@ if __name__ == "__main__":
         main()
         aux_refs()
         adam_trajectory()
+        full_size_c1()

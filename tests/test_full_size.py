@@ -66,6 +66,32 @@ def test_forward_at_baseline_size(recon, name):
           f"max|drgb|={(rgb - o_rgb).abs().max().item():.2e} max|ddepth|={(depth - o_depth).abs().max().item():.2e}")
 
 
+def test_c1_against_the_reference_output_vector(recon):
+    """BASELINE config 1 (128^3, N = 443, 4096 rays) against what the REFERENCE itself rendered on the CPU
+    (tests/golden/full_size_c1.npz, SURVEY §8c's full-size vector; the oracle is pinned to it in
+    tests/test_oracle_golden.py): RGB / depth within 1e-4 relative, shaded-sample count within threshold ties."""
+    from recon_amd import synthetic as S
+    from tests._golden import _npz
+    z = _npz("full_size_c1")
+    model, _, n, ndc, white = S.baseline_scene("C1_vm128", DEV)
+    digest = sum(float(v.double().sum()) for k, v in model.state_dict().items() if not k.startswith("alphaMask"))
+    assert abs(digest - float(z["state_digest"])) <= 1e-7 * abs(digest)      # the same field as the reference's
+    assert n == int(z["n_samples"])
+    rays = torch.from_numpy(z["rays"]).to(DEV)
+    with torch.no_grad():
+        rgb, depth, nv = model(rays, None, white_bg=True, is_train=False, ndc_ray=False, N_samples=n)
+    assert abs(int(nv) - int(z["num_valid"])) <= 3, (int(nv), int(z["num_valid"]))
+    bad = np.abs(rgb.cpu().numpy() - z["rgb_map"]) > ATOL_RGB + RTOL * np.abs(z["rgb_map"])
+    # a sample that flips at the 1e-4 weight threshold moves its ray by ~1e-4: at most as many rays as flipped samples
+    assert bad.any(axis=1).sum() <= abs(int(nv) - int(z["num_valid"])), int(bad.any(axis=1).sum())
+    ok = ~bad.any(axis=1)
+    # depth = sum w z + (1 - acc) d_z (tensorBase.py:387-388): two terms of the size of z (up to far = 6) that cancel for
+    # nearly transparent rays, so the absolute bar is 1e-5 of that scale (two such rays differ by 3e-5 on |depth| = 0.04)
+    np.testing.assert_allclose(depth.cpu().numpy()[ok], z["depth_map"][ok], rtol=RTOL, atol=6e-5)
+    print(f"C1 vs reference vector: shaded {int(nv)} / {int(z['num_valid'])}, max |drgb| "
+          f"{np.abs(rgb.cpu().numpy() - z['rgb_map'])[ok].max():.2e}")
+
+
 class _MaskedRelu(torch.autograd.Function):
     """relu whose derivative is a given on/off pattern (the forward value is the oracle's own)."""
 

@@ -96,6 +96,47 @@ def test_graphed_train_step_matches_eager(recon):
     assert gs.graph is not None
 
 
+def test_graphed_step_follows_per_iteration_free_masks(recon):
+    """`free_reg: true` (configs/config.yaml:62; train.py:303-318 builds a new FreeNeRF mask dict every iteration): the
+    captured step reads its masks from a static device buffer that set_mask() refreshes, so ONE capture serves the whole
+    schedule.  Replayed loss and gradients == the eager step's with the same mask, at the start, the middle and the end
+    of a 3000-iteration mask schedule (lr = 0: the parameters stay put)."""
+    c = Case("vm_cubic_train")
+    dev = "cuda:0"
+    rays = c.rays.to(dev)
+    target = torch.from_numpy(c.expect("grad/target")).to(dev)
+    me, mg = build_model(recon, c, dev), build_model(recon, c, dev)
+    oe, og = torch.optim.SGD(me.parameters(), lr=0.0), torch.optim.SGD(mg.parameters(), lr=0.0)
+
+    def free_mask(step, device):
+        return recon.get_free_mask(pos_bl=me.pos_bit_length, view_bl=me.view_bit_length, fea_bl=me.fea_bit_length,
+                                   den_bl=me.density_n_comp, app_bl=me.app_n_comp, step=step, total_step=3000, device=device)
+
+    gs = recon.GraphedTrainStep(mg, og, rays.shape[0], -1, warmup=1, mask=free_mask(0, "cpu"))
+    captured = None
+    losses = []
+    for it, step in enumerate([0, 0, 0, 500, 1500, 2999, 3000]):
+        torch.manual_seed(200 + it)
+        rgb, _, _ = me(rays, free_mask(step, dev), white_bg=True, is_train=True)
+        loss = torch.mean((rgb - target) ** 2)
+        oe.zero_grad()
+        loss.backward()
+        torch.manual_seed(200 + it)
+        gs.set_mask(free_mask(step, "cpu"))
+        lg = gs.step(rays, target)
+        torch.cuda.synchronize()
+        losses.append(loss.item())
+        assert abs(lg.item() - loss.item()) < 1e-6 * max(1.0, abs(loss.item())), (step, lg.item(), loss.item())
+        for (k, a), (_, b) in zip(me.named_parameters(), mg.named_parameters()):
+            scale = max(a.grad.abs().max().item(), 1e-12)
+            assert (a.grad - b.grad).abs().max().item() <= 1e-4 * scale, (step, k)
+        if gs.graph is not None and captured is None:
+            captured = gs.graph
+        assert captured is None or gs.graph is captured, "a new mask VALUE must not trigger a new capture"
+    assert captured is not None
+    assert abs(losses[3] - losses[2]) > 1e-7 and abs(losses[5] - losses[3]) > 1e-7      # the masks did change the result
+
+
 def test_graphed_adam_training_reduces_loss(recon):
     c = Case("vm_cubic_train")
     dev = "cuda:0"

@@ -232,3 +232,24 @@ def test_cached_launch_descriptors_are_reused_and_follow_the_parameters(recon):
         want, _, _ = twin(rays, None)
         got, _, _ = model(rays, None)
         assert model._plans[False] is not plan and torch.equal(got, want)
+
+
+def test_sh_and_rgb_heads_alone_against_the_reference(recon):
+    """SHRender / RGBRender as stand-alone calls (models/mlp.py:15-25) through tf_shade_points, directly against the
+    reference functions' outputs (tests/golden/sh_head.npz: 300 feature rows and view directions)."""
+    from recon_amd import synthetic as S
+    from tests._golden import _npz
+    z = _npz("sh_head")
+    dev = "cuda:0"
+    feats, dirs = torch.from_numpy(z["feats"]).to(dev), torch.from_numpy(z["dirs"]).to(dev)
+    pts = torch.zeros_like(dirs)
+    aabb = torch.tensor(S.LEGO_AABB, device=dev)
+    sh = recon.TensorVMSplit(S.lego_args("SH", density_n_comp=(4, 4, 4), app_n_comp=(4, 4, 4)), aabb, [8, 8, 8],
+                             S.LEGO_NEAR_FAR, dev)
+    assert sh.renderModule == "SH"
+    np.testing.assert_allclose(sh.renderModule(pts, dirs, feats).cpu().numpy(), z["rgb_sh"], rtol=RTOL, atol=ATOL_RGB)
+    a = S.lego_args("RGB", density_n_comp=(4, 4, 4), app_n_comp=(4, 4, 4))
+    a["app_dim"] = 3
+    rgb = recon.TensorVMSplit(a, aabb, [8, 8, 8], S.LEGO_NEAR_FAR, dev)
+    np.testing.assert_allclose(rgb.renderModule(pts, dirs, feats[:, :3].contiguous()).cpu().numpy(), z["rgb_passthrough"],
+                               rtol=RTOL, atol=ATOL_RGB)

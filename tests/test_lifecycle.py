@@ -75,13 +75,26 @@ def test_alpha_rebuild_filtering_and_schedule_on_gpu(recon):
     assert kept.view(-1).long().tolist() == z["filter_bbox_kept"].tolist()
     _, kept = model.filtering_rays(frays, idx, N_samples=64)
     assert kept.view(-1).long().tolist() == z["filter_alpha_kept"].tolist()
-    # alpha-volume rebuild: same occupancy up to threshold ties, same tight bbox within a voxel
+    # alpha-volume rebuild: the reference's occupancy volume bit for bit — except voxels whose pooled alpha sits ON the
+    # threshold (the lattice alphas are 1 - exp(-sigma * step): the GPU's exp / softplus differ from the CPU's in the
+    # last bits), which are listed with their margins like the ReLU ties of tests/test_full_size.py; the tight box must
+    # be the reference's exactly unless such a tie sits on its face
     new_aabb = model.updateAlphaMask((20, 24, 28))
     got = model.alphaMask.alpha_volume[0, 0].cpu().numpy() > 0.5
     ref = z["upd/alpha"] > 0
-    assert got.shape == ref.shape and (got != ref).mean() < 2e-3, (got != ref).sum()
-    voxel = 3.0 / np.array([19, 23, 27])
-    assert np.all(np.abs(new_aabb.cpu().numpy() - z["upd/new_aabb"]) <= voxel + 1e-6)
+    assert got.shape == ref.shape
+    ties = np.argwhere(got != ref)
+    if len(ties):
+        mdl = make(recon, z, dev)                                    # the state the rebuild started from (alpha0 mask)
+        alpha, _ = mdl.getDenseAlpha((20, 24, 28))                   # (gx, gy, gz), tensorBase.py:215-230
+        pooled = torch.nn.functional.max_pool3d(alpha.clamp(0, 1).permute(2, 1, 0)[None, None], 3, 1, 1)[0, 0].cpu().numpy()
+        margins = np.abs(pooled[tuple(ties.T)] - ARGS["alphaMask_thres"])
+        print("alpha-volume threshold ties (z, y, x) / margin:", [(tuple(t), float(m)) for t, m in zip(ties, margins)])
+        assert len(ties) <= 3 and (margins <= 1e-6).all(), (ties, margins)
+        voxel = 3.0 / np.array([19, 23, 27])
+        assert np.all(np.abs(new_aabb.cpu().numpy() - z["upd/new_aabb"]) <= voxel + 1e-6)
+    else:
+        assert np.array_equal(new_aabb.cpu().numpy(), z["upd/new_aabb"]), (new_aabb, z["upd/new_aabb"])
     # continue the schedule from the reference's own mask / bbox so later steps compare exactly
     model.alphaMask = recon.AlphaGridMask(dev, torch.tensor(CUBE, device=dev), torch.from_numpy(z["upd/alpha"]).float().to(dev))
     model.shrink(torch.from_numpy(z["upd/new_aabb"]).to(dev))

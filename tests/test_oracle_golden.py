@@ -97,3 +97,25 @@ def test_tvloss_matches_reference_fixture(recon):
         assert abs(y.item() - float(z[f"tv/{tag}/loss"])) <= 2e-6 * abs(float(z[f"tv/{tag}/loss"])), tag
         ref = torch.from_numpy(z[f"tv/{tag}/grad"])
         assert (x.grad - ref).abs().max().item() <= 2e-6 * ref.abs().max().item(), tag
+
+
+def test_oracle_at_full_size_c1_against_the_reference_vector(recon):
+    """BASELINE config 1 at its real size (128^3, N = 443, 4096 rays): the oracle against the output vector the
+    reference itself produced (tests/golden/full_size_c1.npz, gen_golden.py `c1`).  The field is rebuilt from its seed
+    (the fixture stores a digest of the state, not 12 MB of parameters)."""
+    from recon_amd import synthetic as S
+    from tests.helpers import oracle_of
+    z = _npz("full_size_c1")
+    model, rays, n, ndc, white = S.baseline_scene("C1_vm128", "cpu")
+    digest = sum(float(v.double().sum()) for k, v in model.state_dict().items() if not k.startswith("alphaMask"))
+    assert abs(digest - float(z["state_digest"])) <= 1e-9 * abs(digest), (digest, float(z["state_digest"]))
+    assert int(model.alphaMask.alpha_volume.sum()) == int(z["alpha_kept"]) and n == int(z["n_samples"])
+    perm = torch.randperm(rays.shape[0], generator=torch.Generator().manual_seed(1))[:4096]
+    assert np.array_equal(rays[perm].numpy(), z["rays"])
+    cfg, params = oracle_of(model, "cpu")
+    with torch.no_grad():
+        rgb, depth, nv = R.render_rays(cfg, params, torch.from_numpy(z["rays"]), None, white_bg=True, is_train=False,
+                                       n_samples=n)
+    assert int(nv) == int(z["num_valid"])
+    np.testing.assert_allclose(rgb.numpy(), z["rgb_map"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(depth.numpy(), z["depth_map"], rtol=1e-6, atol=1e-6)

@@ -35,7 +35,7 @@ def _worker(rank, world, port, q):
     import faulthandler
     import sys
     faulthandler.enable()
-    faulthandler.dump_traceback_later(150, exit=True)     # a rank that hangs reports where, instead of the peer timing out
+    faulthandler.dump_traceback_later(250, exit=True)     # a rank that hangs reports where, instead of the peer timing out
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import recon_amd as recon
     from recon_amd import parallel
@@ -84,6 +84,50 @@ def _worker(rank, world, port, q):
         dist.all_gather(both, digest)
         out["same_params"] = bool(torch.equal(both[0], both[1]))
         out["finite"] = all(bool(torch.isfinite(p).all()) for p in model.parameters())
+        # 2b. no white background (LLFF, llff.py:141 — BASELINE config 4 at 2 GPUs): the random-background draw of
+        #     tensorBase.py:380 picks one of two captured variants per step, the same one on every rank
+        opt_b = recon.FusedAdam(model.get_optparam_groups(0.005, 1e-3), betas=(0.9, 0.99))
+        gs_b = recon.GraphedTrainStep(model, opt_b, ids.numel(), N, warmup=1, white_bg=False)
+        seen = []
+        for it in range(12):
+            float(gs_b.step(rays, target, ids))
+            seen.append(gs_b._bg)
+        torch.cuda.synchronize()
+        flags = torch.tensor([float(b) for b in seen])
+        both_f = [torch.empty_like(flags) for _ in range(world)]
+        dist.all_gather(both_f, flags)
+        out["bg_same_draws"] = bool(torch.equal(both_f[0], both_f[1])) and 0 < sum(seen) < len(seen)
+        out["bg_variants"] = len(gs_b._graphs)
+        digest = torch.stack([p.detach().double().sum() for p in model.parameters()])
+        dist.all_gather(both, digest)
+        out["bg_same_params"] = bool(torch.equal(both[0], both[1]))
+        del gs_b, opt_b
+        # 2c. direct scatter (binned_scatter off): the density line gradients leave their replicas only at the end of the
+        #     backward, so the split step must send ONE bucket after it (round-2 advisor finding)
+        model.binned_scatter = False
+        model._train_ws, model._ws_cache = {}, {}
+        opt_c = recon.FusedAdam(model.get_optparam_groups(0.005, 1e-3), betas=(0.9, 0.99))
+        gs_c = recon.GraphedTrainStep(model, opt_c, ids.numel(), N, warmup=1)
+        for it in range(5):
+            float(gs_c.step(rays, target, ids))
+        torch.cuda.synchronize()
+        out["direct_one_bucket"] = bool(gs_c._one_bucket) and gs_c.graph is not None
+        # the exchanged density-line gradient of the last step == mean of the ranks' local ones (eager, same mode)
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(30 + rank)
+        rgb, _, _ = model(rays[ids], None, white_bg=True, is_train=True, N_samples=N)
+        torch.mean((rgb - target[ids]) ** 2).backward()
+        local = model.grad_flat.clone()
+        parallel.allreduce_gradients(model)
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(parts, local)
+        out["direct_exchange_err"] = float((model.grad_flat - sum(parts) / world).abs().max())
+        del rgb
+        digest = torch.stack([p.detach().double().sum() for p in model.parameters()])
+        dist.all_gather(both, digest)
+        out["direct_same_params"] = bool(torch.equal(both[0], both[1]))
+        model.binned_scatter = True
+        model._train_ws, model._ws_cache = {}, {}
         # 3. sharded evaluation: every rank ends up with the image a single process renders
         def render(block):
             with torch.no_grad():
@@ -108,7 +152,7 @@ def test_two_rank_train_step_on_one_gpu():
     for p in procs:
         p.start()
     try:
-        res = [q.get(timeout=200) for _ in range(world)]
+        res = [q.get(timeout=300) for _ in range(world)]
     except Exception:
         for p in procs:
             p.join(timeout=5)
@@ -121,4 +165,29 @@ def test_two_rank_train_step_on_one_gpu():
         assert r["exchange_err"] <= 1e-6 * r["grad_max"], r
         assert r["split"] and r["graphs"] and r["same_params"] and r["finite"] and r["eval_same"], r
         assert min(r["losses"][3:]) < r["losses"][0], r["losses"]
+        assert r["bg_same_draws"] and r["bg_variants"] == 2 and r["bg_same_params"], r
+        assert r["direct_one_bucket"] and r["direct_same_params"] and r["direct_exchange_err"] <= 1e-6 * r["grad_max"], r
     print("cells exchanged: %.1f %% of the gradient buffer" % (100 * res[0]["cells"]))
+
+
+def test_split_step_over_rccl_in_a_one_rank_group():
+    """The three-graph data-parallel step over backend "nccl" (RCCL) — a one-rank group in a fresh child process
+    (tests/rccl_rehearsal.py; TF_DP_FORCE_EXCHANGE=1): 8 steps with both collectives between the replays must follow
+    the single-graph step's trajectory (the bars of tests/test_hip_backward.py::_same_trajectory), scatter status clean."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_rehearsal.py"), str(_free_port())],
+                       capture_output=True, text=True, timeout=400, cwd=root, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (p.stdout[-1000:], p.stderr[-2000:])
+    r = json.loads(lines[0])
+    print(r)
+    assert r["backend"] == "nccl" and r["world"] == 1
+    assert r["single_graph"] and r["split_graphs"] and r["finite"]
+    assert r["buckets"][0] >= 1 and r["buckets"][1] >= 1 and min(r["bucket_floats"]) > 0      # both buckets really travelled
+    assert r["worst_loss_gap"] <= 2e-3 and r["worst_param_gap_mlp"] <= 0.35 and r["worst_param_gap_other"] <= 0.05, r
