@@ -130,8 +130,8 @@ __device__ __forceinline__ void flag(const TfBinJob& J, int bit) {
     if (J.status) atomicOr(J.status, bit);
 }
 
-constexpr int kScanThreads = 1024;  // the scan runs beside tf_shade_forward on some CU: a small workgroup (4 waves) slows the
-                                   // shading workgroup it shares that CU with far less than 16 waves did
+constexpr int kScanThreads = 1024;  // one 16-wave workgroup per job: the key ranges of a job are dealt over
+                                   // its threads, and it reads nothing from global memory while it scans
 constexpr int kKeyRange = 16384;   // keys per LDS pass of the count / scan / fill kernels (64 KB of ints)
 
 // entries of shard g handled by slice k: local = k*256 + tid, += kSlices*256.  Jobs with more than kKeyRange keys
@@ -358,6 +358,15 @@ __device__ __forceinline__ float rlf(float v, int k) { return __int_as_float(__b
 // entries a wave stages per round (LDS per wave: ER x (C + 8) floats).  16: with 32 the staging rows put a workgroup at
 // 33 KB of LDS, four per CU; at 27 KB and 96 VGPRs five fit (20 waves per CU to hide the stage's gathers behind):
 // 0.706 -> 0.694 ms per captured step at config 2
+// Lanes of a wave exchange data through the wave's own LDS rows between two phases of a round: make the writes visible
+// to the other lanes AND keep the compiler from moving the following LDS reads above this point (a release-only fence
+// orders the stores; the loads behind it need the acquire half).
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 __host__ __device__ inline int entries_per_round(int cmax) { (void)cmax; return 16; }
 __host__ __device__ inline int lane_group(int c) { return c <= 16 ? 16 : (c <= 32 ? 32 : 64); }
 
@@ -480,8 +489,7 @@ __global__ __launch_bounds__(256, 5) void bin_scatter_kernel(const TfBinJob J, c
             // No workgroup barrier inside the rounds: the staging rows, the meta rows and the accumulation block are this
             // wave's own, and a wave's LDS operations execute in order — the four waves drift apart and fill each other's
             // memory waits instead of meeting twice per round.
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            wave_sync_lds();
             TF_MARK(1);
             // ---------------- stage: LPE = 64 / ER lanes per entry, lane `sub` takes channel quads sub, sub+LPE, ...
             if (ent < nk && e_cur < 0) {     // a rejected entry contributes nothing
@@ -549,8 +557,7 @@ __global__ __launch_bounds__(256, 5) void bin_scatter_kernel(const TfBinJob J, c
                     }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            wave_sync_lds();
             TF_MARK(2);
             // ---------------- accumulate (private block, plain read-add-write)
             const int nfoot = is_line ? 2 * C : 4 * C;

@@ -80,7 +80,9 @@ __host__ __device__ inline int tile_col(int NT, int t, int j) {
 
 // acc[ea][eb] += sum_s A[s][a0 + EA i + ea] * B[s][b0 + EB j + eb]  (s = 0 .. 4 ksteps - 1), both operands in LDS,
 // sample-major rows: the "TN" weight-gradient GEMM.  Software-pipelined one k-step ahead.
-template <int EA, int EB>
+// HILO_A: the A operand is stored as [hi | lo] words (tf_shade.h): its values are rebuilt (hi + lo, 16 mantissa bits) as
+// they are read — the weight-gradient sums stay on the fp32 pipe.
+template <int EA, int EB, bool HILO_A = false>
 __device__ __forceinline__ void tn_block(const float* A, int lda, int a0, const float* B, int ldb, int b0, int ksteps,
                                           f32x4 (&acc)[EA][EB], int lane) {
     const int r = lane & 15, kq = lane >> 4;
@@ -95,6 +97,10 @@ __device__ __forceinline__ void tn_block(const float* A, int lda, int a0, const 
         const int tn = t + 1 < ksteps ? t + 1 : t;
         ldv<EA>(ap + 4 * tn * lda, an);
         ldv<EB>(bp + 4 * tn * ldb, bn);
+        if constexpr (HILO_A) {
+#pragma unroll
+            for (int ea = 0; ea < EA; ++ea) a[ea] = unpack_hilo(a[ea]);
+        }
 #pragma unroll
         for (int ea = 0; ea < EA; ++ea)
 #pragma unroll
@@ -104,6 +110,43 @@ __device__ __forceinline__ void tn_block(const float* A, int lda, int a0, const 
         for (int ea = 0; ea < EA; ++ea) a[ea] = an[ea];
 #pragma unroll
         for (int eb = 0; eb < EB; ++eb) b[eb] = bn[eb];
+    }
+}
+
+// The weight-gradient ("TN") GEMM on the bf16 matrix pipe: acc[ta][tb] += sum_s A[s][a0 + 16 ta + i] * B[s][b0 + 16 tb + j]
+// over `ksteps` blocks of 16 samples, A stored as [hi | lo] words (a dZ matrix), B in fp32 (a saved activation matrix,
+// split in registers like a weight fragment: tf_shade.h).  The k index of the K = 32 instruction is the SAMPLE: lane
+// (idx, g) holds samples 16 t + 4 g .. + 3 of column idx — four 4-byte LDS reads from four consecutive rows per
+// fragment.  Rows are 4 (mod 64) words apart (strides 68 / 132 / 164), so the 64 lanes of a read hit the 64 banks once.
+// Tiles are plain 16 x 16 blocks (the fp32 tn_block interleaves them): wslab_reduce_kernel maps them back.
+template <int TA, int TB>
+__device__ __forceinline__ void tn_block_hilo(const float* A, int lda, int a0, const float* B, int ldb, int b0, int ksteps,
+                                               f32x4 (&acc)[TA][TB], int lane) {
+    const int r = lane & 15, g = lane >> 4;
+    const float* ap = A + 4 * g * lda + a0 + r;
+    const float* bp = B + 4 * g * ldb + b0 + r;
+#pragma unroll 1
+    for (int t = 0; t < ksteps; ++t) {
+        f32x4 aw[TA], bw[TB];
+#pragma unroll
+        for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) aw[ta][e] = ap[(16 * t + e) * lda + 16 * ta];
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bw[tb][e] = bp[(16 * t + e) * ldb + 16 * tb];
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) {
+            bf16x8 b1, b2;
+            split_weight_frag(bw[tb], b1, b2);
+#pragma unroll
+            for (int ta = 0; ta < TA; ++ta)
+                acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aw[ta]), b1, acc[ta][tb], 0, 0, 0);
+#pragma unroll
+            for (int ta = 0; ta < TA; ++ta)
+                acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aw[ta]), b2, acc[ta][tb], 0, 0, 0);
+        }
     }
 }
 
@@ -234,10 +277,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
     constexpr bool WIDE = MODE == 1, BLDS = MODE == 0;
     constexpr int NT = 512, NW = 8, SG = NW / FT, NSW = 4 / SG;
     constexpr int FCc = 16 * FT, EA2 = FCc / 32, EB2 = FCc / 64, EA1 = FCc / 64;
-#ifndef TF_KTBW
-#define TF_KTBW 3
-#endif
-    constexpr int KTBW = TF_KTBW;          // dB: column tiles wave, wave + 8, wave + 16 (n_app_total <= 384)
+    constexpr int KTBW = 3;                // dB: column tiles wave, wave + 8, wave + 16 (n_app_total <= 384)
     const BwdLds L = bwd_lds(S);
     float* DZ1 = lds + L.offV;            // dZ1 [64][sh]; later V [64][sv]
     float* V = lds + L.offV;
@@ -377,7 +417,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                     tW3[1] = fmaf(d[i][1], h[i], tW3[1]);
                     tW3[2] = fmaf(d[i][2], h[i], tW3[2]);
                     const float dz = h[i] > 0.f ? fmaf(d[i][2], w2, fmaf(d[i][1], w1, d[i][0] * w0)) : 0.f;
-                    hp[i * L.sh] = dz;
+                    hp[i * L.sh] = pack_hilo(dz);          // dZ2 as [hi | lo] words: operand of the bf16 data-gradient product
                     tb2 += dz;
                 }
             }
@@ -391,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         {
             f32x4 acc[1][NSW];
             zero_acc(acc);
-            mma_frags<1, NSW, FT>(fr3, H2, L.sh, s_base, FT, acc, lane);
+            mma_frags_hilo<NSW, FT>(fr3, H2, L.sh, s_base, FT, acc, lane);
             if (wave < 2 * kt1) load_a_frags<1, FT>(S.w1t, FCc, 16 * (wave >> 1), FT, lane, frx[0]);
             const int f = 16 * my_ft + 4 * lg;
 #pragma unroll
@@ -403,6 +443,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                 for (int e = 0; e < 4; ++e) {
                     dz[e] = h[e] > 0.f ? acc[0][j][e] : 0.f;
                     ab1[e] += dz[e];
+                    dz[e] = pack_hilo(dz[e]);              // dZ1 leaves as [hi | lo] words too (dX = W1^T dZ1 below)
                 }
                 *reinterpret_cast<f32x4*>(DZ1 + s * L.sh + f) = dz;
             }
@@ -410,7 +451,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
             TF_MARK(3);
             dma_rows(xs, xq4, X, sxq, inv_sxq, n, wave, lane, [&](int r) { return ck.at(r); });     // for P5, lands behind dW2
             // dW2[f2][f1]: wave -> (f2 block of FC/2, f1 block of FC/4)
-            tn_block<EA2, EB2>(H2, L.sh, (FCc / 2) * (wave >> 2), H1, L.sh, (FCc / 4) * (wave & 3), M / 4, aW2, lane);
+            tn_block_hilo<EA2, EB2>(H2, L.sh, (FCc / 2) * (wave >> 2), H1, L.sh, (FCc / 4) * (wave & 3), M / 16, aW2, lane);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of X are in LDS
         lds_barrier();
@@ -419,28 +460,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         // ================= P5: dW1 += dZ1^T X;  dX = W1^T dZ1 -> DX (over H1 | H2) =================
         {
             // dW1[f][k]: wave -> (f block of FC/4 columns of dZ1, half of the k tiles of X)
-            const int r = lane & 15, kq = lane >> 4;
-            const float* ap = DZ1 + kq * L.sh + (FCc / 4) * (wave >> 1) + EA1 * r;
-            const float* bp = X + kq * L.sx + 16 * NTW * (wave & 1);
-            float a[EA1], b[NTW];
-            ldv<EA1>(ap, a);
-            ld_tiles<NTW>(bp, r, b);
-#pragma unroll 2
-            for (int t = 0; t < M / 4; ++t) {
-                float an[EA1], bn[NTW];
-                const int tn = t + 1 < M / 4 ? t + 1 : t;
-                ldv<EA1>(ap + 4 * tn * L.sh, an);
-                ld_tiles<NTW>(bp + 4 * tn * L.sx, r, bn);
-#pragma unroll
-                for (int ea = 0; ea < EA1; ++ea)
-#pragma unroll
-                    for (int eb = 0; eb < NTW; ++eb)
-                        aW1[ea][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ea], b[eb], aW1[ea][eb], 0, 0, 0);
-#pragma unroll
-                for (int ea = 0; ea < EA1; ++ea) a[ea] = an[ea];
-#pragma unroll
-                for (int eb = 0; eb < NTW; ++eb) b[eb] = bn[eb];
-            }
+            tn_block_hilo<EA1, NTW>(DZ1, L.sh, (FCc / 4) * (wave >> 1), X, L.sx, 16 * NTW * (wave & 1), M / 16, aW1, lane);
         }
         TF_MARK(5);
         // dX[k][s] = sum_f W1[f][k] dZ1[s][f].  Work items are (k tile, pair of sample tiles): 2 kt1 items dealt
@@ -453,7 +473,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
                 if (round > 0) load_a_frags<1, FT>(S.w1t, FCc, 16 * kt, FT, lane, frx[0]);
                 f32x4 acc[1][2];
                 zero_acc(acc);
-                mma_frags<1, 2, FT>(frx[0], DZ1, L.sh, 32 * sp, FT, acc, lane);
+                mma_frags_hilo<2, FT>(frx[0], DZ1, L.sh, 32 * sp, FT, acc, lane);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     *reinterpret_cast<f32x4*>(DX + (32 * sp + 16 * j + lc) * L.sx + 16 * kt + 4 * lg) = acc[0][j];
@@ -655,9 +675,6 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
             // floats of tail padding): those columns are computed and dropped.  The accumulators go straight to dv_out,
             // ahead of the dB loop, so that the stores have retired when the next chunk waits for its X rows.
             const int r = lane & 15, kq = lane >> 4;
-#ifdef TF_X_NODV
-            if (0)
-#endif
             for (int u = NW - 1 - wave; u < n_units; u += NW) {
                 const int st = u & 3, cb = 64 * (u >> 2), un = u + NW;
                 const float* bp = Fd + (16 * st + r) * L.sf + kq;
@@ -822,11 +839,11 @@ __global__ __launch_bounds__(1024) void wslab_reduce_kernel(const TfShade S, con
         const int i = 4 * (lane >> 4) + e;
         if (tile < T.n2) {            // dW2 tile (wave, ea, eb)
             const int eb = tile % T.EB2, ea = (tile / T.EB2) % T.EA2, w = tile / (T.EA2 * T.EB2);
-            const int f2 = (T.FC / 2) * (w >> 2) + T.EA2 * i + ea, f1 = (T.FC / 4) * (w & 3) + T.EB2 * j + eb;
+            const int f2 = (T.FC / 2) * (w >> 2) + 16 * ea + i, f1 = (T.FC / 4) * (w & 3) + 16 * eb + j;
             G.w2[(size_t)f2 * T.FC + f1] = a[e];
         } else if (tile < T.n2 + T.n1) {   // dW1 tile (wave, ea, t)
             const int t2 = tile - T.n2, t = t2 % T.NTW, ea = (t2 / T.NTW) % T.EA1, w = t2 / (T.NTW * T.EA1);
-            const int f = (T.FC / 4) * (w >> 1) + T.EA1 * i + ea, k = 16 * T.NTW * (w & 1) + tile_col(T.NTW, t, j);
+            const int f = (T.FC / 4) * (w >> 1) + 16 * ea + i, k = 16 * T.NTW * (w & 1) + 16 * t + j;
             if (k < S.in_c) G.w1[(size_t)f * S.in_c + k] = a[e];
         } else {                      // dB tile (e_f, column tile)
             const int t3 = tile - T.n2 - T.n1, ct = t3 % T.ktB, ef = t3 / T.ktB;
@@ -899,9 +916,6 @@ bwd_fn_t pick_ntw(int ntw, int mode) {
 }
 
 bwd_fn_t pick_bwd(const TfShade& S) {
-#ifdef TF_ONLY_C2     // compile-time experiments: the benchmark configuration only
-    return shade_backward_kernel<8, 2, 5, 0>;
-#else
     const int nb = (S.app_dim + 15) / 16, kt1 = kpad16(S.in_c) / 16;
     if (S.head != TF_HEAD_MLP || nb > 2 || kt1 > 12 || kpad16(S.n_app_total) / 16 > 24) return nullptr;
     const BwdLds L = bwd_lds(S);
@@ -915,7 +929,6 @@ bwd_fn_t pick_bwd(const TfShade& S) {
     if (S.feature_c == 64) return nb == 1 ? pick_ntw<4, 1>(ntw, mode) : pick_ntw<4, 2>(ntw, mode);
     if (S.feature_c == 128) return nb == 1 ? pick_ntw<8, 1>(ntw, mode) : pick_ntw<8, 2>(ntw, mode);
     return nullptr;
-#endif
 }
 
 }  // namespace
@@ -935,7 +948,8 @@ int tf_shade_backward(const TfShade* shade, const float* rays, int ndc, const in
     const size_t bytes = (size_t)L.total * sizeof(float);
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(fn), (size_t)(bytes));
     if (e != hipSuccess) return (int)e;
-    if (!grads->dv_out || !grads->wslab || !grads->x_saved || !grads->rgb_fwd || !shade->w1t || !shade->w2t)
+    if (!grads->dv_out || !grads->wslab || !grads->x_saved || !grads->h1_saved || !grads->h2_saved || !grads->rgb_fwd ||
+        !shade->w1t || !shade->w2t)
         return (int)hipErrorInvalidValue;
     TileSrc src{counters, seg_cap, 0, app_ray, app_xyz, rays, ndc, nullptr, nullptr};
 #ifdef TF_PHASE_TIMING

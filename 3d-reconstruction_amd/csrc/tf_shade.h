@@ -59,14 +59,8 @@ __device__ __forceinline__ void mma_block(const float* __restrict__ Wg, int ldw,
         const int kga = kg + 2 < kgroups ? kg + 2 : kg, kgb = kg + 1 < kgroups ? kg + 1 : kg;   // tail: harmless re-reads
 #pragma unroll
         for (int i = 0; i < NF; ++i) a2[i] = *reinterpret_cast<const f32x4*>(wp + (size_t)16 * i * ldw + 16 * kga);
-#ifdef TF_B_SINGLE
-#pragma unroll
-        for (int j = 0; j < NS; ++j) b0[j] = *reinterpret_cast<const f32x4*>(xp + 16 * j * ldx + 16 * kg);
-        (void)kgb;
-#else
 #pragma unroll
         for (int j = 0; j < NS; ++j) b1[j] = *reinterpret_cast<const f32x4*>(xp + 16 * j * ldx + 16 * kgb);
-#endif
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -79,10 +73,8 @@ __device__ __forceinline__ void mma_block(const float* __restrict__ Wg, int ldw,
             a0[i] = a1[i];
             a1[i] = a2[i];
         }
-#ifndef TF_B_SINGLE
 #pragma unroll
         for (int j = 0; j < NS; ++j) b0[j] = b1[j];
-#endif
     }
 }
 
@@ -140,6 +132,78 @@ __device__ __forceinline__ void mma_frags(const f32x4 (&a)[KG][NF], const float*
                         acc[i][PW * pr + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kg][i][e], b[st & 1][j][e], acc[i][PW * pr + j], 0, 0, 0);
         }
     }
+}
+
+// ---- data-gradient GEMMs of the backward on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16: 16 x the fp32 rate) -------
+// An activation x is kept in LDS as ONE 32-bit word  [ hi | lo ]:  hi = the upper 16 bits of x (a bf16, truncated), lo =
+// the bf16 nearest to x - hi — x to 16 mantissa bits in the 4 bytes the fp32 took.  A lane's 16-byte LDS read of four
+// consecutive words IS a B fragment of the K = 32 instruction with the k index interleaved: k' = 2k holds lo_k, 2k + 1
+// holds hi_k (four real k per lane, sixteen per instruction — the k = 16 kg + 4 kq + e of the fp32 path, so the same
+// addresses).  The weight fragment w (fp32 from L2, split in registers) meets it twice:
+//     A1 = [wh, wh] per word:  sum wh (lo + hi)        A2 = [0, wl] per word:  sum wl hi
+// = wh xh + wh xl + wl xh: every product but lo.lo, error ~1e-5 of the result's largest entry (fp32 pipe: 3e-7;
+// profiles/r02_mfma_bf16_split_probe.txt), two MFMAs of 16 cycles per 16 k where the fp32 path issues four of 32: 4 x.
+// Only the BACKWARD's data-gradient products use it (dZ1 = W2^T dZ2, dX = W1^T dZ1): its ReLU masks come from the
+// forward's SAVED activations, so no unit can switch, and the gradient bar (2e-4 of a tensor's maximum) has room.  The
+// forward keeps fp32: a pre-activation moved by 1e-5 switches ReLU units against the reference.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float pack_hilo(float x) {
+    const unsigned b = __float_as_uint(x), hb = b & 0xFFFF0000u;
+    const unsigned r = __float_as_uint(x - __uint_as_float(hb));                 // exact
+    return __uint_as_float(hb | ((r + 0x7FFFu + ((r >> 16) & 1u)) >> 16));       // lo: round to nearest even
+}
+__device__ __forceinline__ float unpack_hilo(float w) {
+    const unsigned b = __float_as_uint(w);
+    return __uint_as_float(b & 0xFFFF0000u) + __uint_as_float(b << 16);
+}
+// fp32 weight fragment (four consecutive k of one row) -> the two A operands above
+__device__ __forceinline__ void split_weight_frag(const f32x4& w, bf16x8& a1, bf16x8& a2) {
+    u32x4 p1, p2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned b = __float_as_uint(w[e]), hb = b & 0xFFFF0000u;
+        const unsigned r = __float_as_uint(w[e] - __uint_as_float(hb));
+        p1[e] = hb | (hb >> 16);
+        p2[e] = (r + 0x7FFFu + ((r >> 16) & 1u)) & 0xFFFF0000u;
+    }
+    a1 = __builtin_bit_cast(bf16x8, p1);
+    a2 = __builtin_bit_cast(bf16x8, p2);
+}
+// mma_frags with the activations as [hi | lo] words in LDS (one feature tile per wave): acc[0][j] += W X^T as above.  The
+// two products of a tile go to separate accumulator chains (hi-weights, lo-weights), summed at the end, so that 2 NS
+// independent MFMAs lie between dependent ones.
+template <int NS, int KG>
+__device__ __forceinline__ void mma_frags_hilo(const f32x4 (&a)[KG][1], const float* Xs, int ldx, int s_base, int kgroups,
+                                               f32x4 (&acc)[1][NS], int lane) {
+    const int r = lane & 15, kq = lane >> 4;
+    const float* xp = Xs + (s_base + r) * ldx + 4 * kq;
+    f32x4 lo_acc[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) lo_acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 b[2][NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) b[0][j] = *reinterpret_cast<const f32x4*>(xp + 16 * j * ldx);
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) {
+        if (kg < kgroups) {
+            if (kg + 1 < KG && kg + 1 < kgroups) {
+#pragma unroll
+                for (int j = 0; j < NS; ++j) b[(kg + 1) & 1][j] = *reinterpret_cast<const f32x4*>(xp + 16 * j * ldx + 16 * (kg + 1));
+            }
+            bf16x8 a1, a2;
+            split_weight_frag(a[kg][0], a1, a2);
+#pragma unroll
+            for (int j = 0; j < NS; ++j)
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, __builtin_bit_cast(bf16x8, b[kg & 1][j]), acc[0][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NS; ++j)
+                lo_acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, __builtin_bit_cast(bf16x8, b[kg & 1][j]), lo_acc[j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NS; ++j) acc[0][j] += lo_acc[j];
 }
 
 // Products (P*m)(L*m) [VM] or (L0*L1*L2)*m [CP] of one sample, channel quads sub, sub+4, ..., written to
