@@ -50,7 +50,8 @@ class TfMarchIO(C.Structure):
                 ("acc", _fp), ("depth", _fp), ("app_offset", _fp), ("app_count", _fp), ("val_count", _fp),
                 ("counters", _fp), ("app_ray", _fp), ("app_xyz", _fp), ("app_w", _fp),
                 ("val_idx", _fp), ("val_feat", _fp), ("dbg_bbox_bits", _fp), ("dbg_valid_bits", _fp),
-                ("dbg_app_bits", _fp), ("ent_xyz", _fp), ("ent_offset", _fp), ("dbg_z", _fp)]
+                ("dbg_app_bits", _fp), ("ent_xyz", _fp), ("ent_offset", _fp), ("dbg_z", _fp), ("seg_cap", C.c_int),
+                ("ent_seg_cap", C.c_int)]
 
 
 class TfPeBlock(C.Structure):
@@ -133,11 +134,25 @@ REG_ORTHO, REG_L1, REG_TV_DENSITY, REG_TV_APP = 1 << 4, 2 << 4, 4 << 4, 8 << 4
 
 
 class TfLive(C.Structure):
-    _fields_ = [("dev", _fp), ("host", _fp)]
+    _fields_ = [("dev", _fp), ("host", _fp), ("slot", _fp), ("n_slots", C.c_int), ("pad_", C.c_int)]
+
+
+OVERFLOW_SLOT = 5
 
 
 class HipError(RuntimeError):
     pass
+
+
+class WorkspaceOverflow(HipError):
+    """A training step produced more samples than its right-sized workspace holds: its gradients are incomplete (and
+    FusedAdam's device-side gate would refuse them).  Raised from `loss.backward()`, AFTER the model has enlarged its
+    workspace for the next call; `jitter` / `z_table` / `use_bg` are the step's random draws:
+    `model.retry_on_overflow(step_fn)` runs the step again with them (harness.train and bench.py do)."""
+
+    def __init__(self, msg, jitter=None, z_table=None, use_bg=None):
+        super().__init__(msg)
+        self.jitter, self.z_table, self.use_bg = jitter, z_table, use_bg
 
 
 _lib = None

@@ -86,7 +86,7 @@ def _bin_job(model, ws, part, factors, grid, stage, fgrads=None, grad=None, grad
     if fgrads is not None:
         j.grads = fgrads
     j.grid = grid
-    j.counters, j.slot, j.seg_cap = ws.counters.data_ptr(), (0 if app else 3), ws.seg_cap
+    j.counters, j.slot, j.seg_cap = ws.counters.data_ptr(), (0 if app else 3), (ws.seg_cap if app else ws.ent_seg_cap)
     j.xyz = (ws.app_xyz if app else ws.ent_xyz).data_ptr()
     j.grad, j.grad_ld = (grad.data_ptr() if grad is not None else None), grad_ld
     j.tile, j.bucket, j.chunk = ws.binned_cfg[3], model.bin_bucket, (model.bin_chunk if share else model.bin_chunk_early)
@@ -98,7 +98,7 @@ def _bin_job(model, ws, part, factors, grid, stage, fgrads=None, grad=None, grad
     j.binned, j.nkeys = (ws.binned_app if app else ws.binned).data_ptr(), nkeys
     j.stage = stage
     # capacities the kernels check every position against (TfBinJob.status collects violations)
-    j.binned_cap = ws.binned_len
+    j.binned_cap = ws.binned_app_len if app else ws.binned_len
     j.items_cap = ws.bin_ints_len - (2 * (nmax + 8) + nkeys + 1)      # ints behind chunk_off[nkeys + 1]
     j.status = ws.bin_status.data_ptr()
     return j
@@ -167,7 +167,30 @@ class _RenderFn(torch.autograd.Function):
             # counts were written to pinned memory by the forward's compositing launch; its event has usually fired by now
             # (the wait is on the forward only, the backward launches above are already queued).
             slot[1].synchronize()
-            n_density, n_shaded = slot[0].tolist()
+            n_density, n_shaded, overflow, _ = slot[0].tolist()
+            ws = c['ws']
+            if ws.right_sized:
+                if overflow:      # this batch did not fit its workspace: the gradients above are incomplete
+                    ctr = ws.counters2d[:, :2].cpu()
+                    model._grow_caps(ws.R, ws.N, int(ctr[:, 0].max()), int(ctr[:, 1].max()))
+                    ctx.c = None
+                    raise H.WorkspaceOverflow(
+                        f"training batch needs {int(ctr[:, 0].max())} shaded / {int(ctr[:, 1].max())} density entries per shard, "
+                        f"the workspace holds {ws.seg_cap} / {ws.ent_seg_cap}: it has been enlarged — run the step again "
+                        f"(model.retry_on_overflow(step_fn) repeats it with the same random draws)",
+                        jitter=c['keep'][3], z_table=c['keep'][4], use_bg=c['use_bg'])
+                # Room is added BEFORE it runs out (shards fill unevenly: 1.15 x the mean is taken for the fullest).  While a
+                # young field's sample counts multiply from step to step the headroom follows their growth rate r (room
+                # for r^2 x the present demand, at most 4 x); once they settle it is 1.3 x.
+                per = 1.15 / H.N_SHARDS
+                need = (n_shaded * per, n_density * per)
+                prev = model._need_prev.get((ws.R, ws.N), (0.0, 0.0))
+                model._need_prev[(ws.R, ws.N)] = need
+                f = [min(4.0, max(1.3, (need[i] / prev[i]) ** 2 if prev[i] > 0 else 1.3)) for i in (0, 1)]
+                if need[0] * f[0] > ws.seg_cap or need[1] * f[1] > ws.ent_seg_cap:
+                    model._grow_caps(ws.R, ws.N, need[0] * f[0] / 1.3, need[1] * f[1] / 1.3)
+            if not model.reference_none_grads:
+                n_density = n_shaded = 1
         out = tuple((grads[n] if (n_density if n.startswith('density_') else n_shaded) else None) if p.requires_grad else None
                     for n, p in named)
         ctx.c = None

@@ -17,6 +17,7 @@ static_assert(TF_ADAM_CHUNK == 8192, "the touched word holds 4 waves x 8 rounds 
 // Is segment s updated by this launch?  (TfAdamJob: host skip mask, sample-count gate, regulariser flags.)
 __device__ __forceinline__ bool seg_open(const TfAdamJob& J, int s) {
     if ((J.skip_mask >> s) & 1u) return false;
+    if (J.live && J.live[2] != 0.f) return false;      // a right-sized list of this step ran full: its gradients are incomplete
     const int gate = J.seg[s].gate;
     const int cnt = gate & 3;
     if (!cnt || !J.live) return true;
@@ -52,8 +53,25 @@ __global__ __launch_bounds__(256) void adam_kernel(const TfAdamJob J) {
         s_hyp[0] = (float)((double)J.lrs[J.seg[s].group] / (double)(float)bc1);   // step size
         s_hyp[1] = (float)sqrt(bc2);
     }
+    __shared__ int s_seg_any;
+    if (tid == 0) {
+        int s = 0;
+        while (s + 1 < J.n_seg && (int)blockIdx.x >= J.chunk_end[s]) ++s;
+        s_seg_any = s;
+    }
     __syncthreads();
     if (s_seg < 0) {         // a parameter without a gradient this step: untouched, like torch.optim.Adam's `grad is None`
+        // ... but a caller that accumulates the next step into the same buffer (clear_grads) must get it back clean: a
+        // step whose lists overflowed leaves INCOMPLETE non-zero gradients behind, which are dropped here
+        if (J.clear_grads && !((J.skip_mask >> s_seg_any) & 1u)) {
+            const TfAdamSeg& sc = J.seg[s_seg_any];
+            const long long c0 = (long long)((int)blockIdx.x - (s_seg_any ? J.chunk_end[s_seg_any - 1] : 0)) * kChunk;
+            const long long n = sc.n - c0 < kChunk ? sc.n - c0 : kChunk;
+            float* __restrict__ g = const_cast<float*>(sc.g) + c0;
+            for (long long i = tid; i < n; i += 256)
+                if (g[i] != 0.f) g[i] = 0.f;
+        }
+        __syncthreads();
         if (tid == 0) arrive(J);
         return;
     }

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kSortThreads) void bin_count_kernel(const SortArgs 
     const TfBinJob& J = A.J[which];
     const KeyMap& K = A.K[which];
     const int g = bid / kSlices, k = bid % kSlices;
-    const int cnt = J.counters[g * TF_SHARD_STRIDE + J.slot];
+    const int cnt = min(J.counters[g * TF_SHARD_STRIDE + J.slot], J.seg_cap);      // (the counter holds the demand)
     for (int k0 = 0; k0 < K.nkeys; k0 += kKeyRange) {
         const int kn = min(kKeyRange, K.nkeys - k0);
         for (int i = threadIdx.x; i < kn; i += kSortThreads) lh[i] = 0;
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(kSortThreads) void bin_fill_kernel(const SortArgs A
     const TfBinJob& J = A.J[which];
     const KeyMap& K = A.K[which];
     const int g = bid / kSlices, k = bid % kSlices;
-    const int cnt = J.counters[g * TF_SHARD_STRIDE + J.slot];
+    const int cnt = min(J.counters[g * TF_SHARD_STRIDE + J.slot], J.seg_cap);      // (the counter holds the demand)
     for (int k0 = 0; k0 < K.nkeys; k0 += kKeyRange) {     // key ranges, as in bin_count_kernel
         const int kn = min(kKeyRange, K.nkeys - k0);
         for (int i = threadIdx.x; i < kn; i += kSortThreads) lh[i] = 0;

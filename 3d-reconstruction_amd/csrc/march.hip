@@ -200,27 +200,36 @@ __global__ __launch_bounds__(64) void march_forward_kernel(const TfField F, cons
     const float acc = wave_sum(acc_l);
     float dep = wave_sum(dep_l);
     dep = dep + (1.f - acc) * io.rays[(size_t)r * 6 + 5];     // tensorBase.py:388 (last ray column, d_z)
-    int base = 0, eb = 0;
+    int base = 0, eb = 0, keep_a = 0, keep_e = 0;
     if (lane == 0) {
         int* ctr = io.counters + shard * kShardStride;
-        const int seg_cap = ((gridDim.x + kShards - 1) / kShards) * N;
+        const int worst = ((gridDim.x + kShards - 1) / kShards) * N;
+        const int seg_cap = io.seg_cap > 0 ? io.seg_cap : worst, ent_cap = io.ent_seg_cap > 0 ? io.ent_seg_cap : worst;
         // the two reservations are requested together (one after the other they were two memory round trips in a row)
         const int a0 = appcnt ? atomicAdd(&ctr[0], appcnt) : 0;
         const int a3 = (io.ent_xyz && done) ? atomicAdd(&ctr[3], done) : 0;
-        base = shard * seg_cap + a0;
-        eb = shard * seg_cap + a3;
-        atomicAdd(&ctr[1], done);
+        // right-sized lists: what does not fit the shard is dropped (the counters keep the demand) and the step is flagged
+        keep_a = max(0, min(appcnt, seg_cap - a0));
+        keep_e = io.ent_xyz ? max(0, min(done, ent_cap - a3)) : 0;
+        const int over = (keep_a < appcnt ? 1 : 0) | ((io.ent_xyz && keep_e < done) ? 2 : 0);
+        if (over) atomicOr(&io.counters[TF_OVERFLOW_SLOT], over);
+        base = shard * seg_cap + min(a0, seg_cap);
+        eb = shard * ent_cap + min(a3, ent_cap);
+        const int a1 = atomicAdd(&ctr[1], done);
+        // (without early sorting the backward reserves the density entries — one per valid sample: the same demand)
+        if (io.save_valid && a1 + done > ent_cap) atomicOr(&io.counters[TF_OVERFLOW_SLOT], 2);
         atomicAdd(&ctr[2], nbbox);
         io.acc[r] = acc;
         io.depth[r] = dep;
         io.app_offset[r] = base;
-        io.app_count[r] = appcnt;
+        io.app_count[r] = keep_a;
         io.val_count[r] = done;
         if (io.ent_xyz) io.ent_offset[r] = eb;
     }
     if (io.ent_xyz) {      // density entry list of the binned backward scatter: coordinates now, dL/df in the backward
         eb = __shfl(eb, 0, 64);
-        for (int k = lane; k < done; k += 64) {
+        keep_e = __shfl(keep_e, 0, 64);
+        for (int k = lane; k < keep_e; k += 64) {
             float p[3], u[3];
             sample_pos(ray, sample_z(F, ray, ztab, q[k]), p);      // (the queue still holds the density samples)
             normalize(F, p, u);
@@ -231,7 +240,8 @@ __global__ __launch_bounds__(64) void march_forward_kernel(const TfField F, cons
         }
     }
     base = __shfl(base, 0, 64);
-    for (int j = lane; j < appcnt; j += 64) {
+    keep_a = __shfl(keep_a, 0, 64);
+    for (int j = lane; j < keep_a; j += 64) {
         const int idx = qs[j];
         float p[3], u[3];
         sample_pos(ray, sample_z(F, ray, ztab, idx), p);
@@ -349,6 +359,7 @@ __global__ __launch_bounds__(256) void composite_kernel(int n_rays, const int* _
         // and the autograd binding: ray_valid.any() / app_mask.any() decide which parameters the reference's graph holds
         // (tensorBase.py:359, :370)
         long long shaded = counters[threadIdx.x * kShardStride], density = counters[threadIdx.x * kShardStride + 1];
+        const int over = counters[TF_OVERFLOW_SLOT];
         static_assert(kShards == 64, "one shard per lane");
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -360,10 +371,16 @@ __global__ __launch_bounds__(256) void composite_kernel(int n_rays, const int* _
             if (live.dev) {
                 live.dev[0] = (float)density;
                 live.dev[1] = (float)shaded;
+                live.dev[2] = (float)over;
             }
             if (live.host) {
-                live.host[0] = (int)(density > 0x7fffffff ? 0x7fffffff : density);
-                live.host[1] = (int)(shaded > 0x7fffffff ? 0x7fffffff : shaded);
+                const int sl = (live.slot && live.n_slots > 0) ? ((int)*live.slot % live.n_slots + live.n_slots) % live.n_slots : 0;
+                int* h = live.host + 4 * sl;
+                h[0] = (int)(density > 0x7fffffff ? 0x7fffffff : density);
+                h[1] = (int)(shaded > 0x7fffffff ? 0x7fffffff : shaded);
+                h[2] = over;
+                __threadfence_system();
+                h[3] = h[3] + 1;       // (number of reports this slot has taken: the host sees a step's words are in)
             }
         }
     }
@@ -498,7 +515,7 @@ int tf_composite_forward(int n_rays, const int* app_offset, const int* app_count
     if (n_rays <= 0) return 0;
     hipLaunchKernelGGL(composite_kernel, dim3((n_rays + 31) / 32), dim3(256), 0, (hipStream_t)stream, n_rays,
                        app_offset, app_count, app_w, rgb, acc, white_bg, rgb_map, rgb_pre, counters, n_shaded,
-                       TfLossFuse{nullptr, 0.f, nullptr, nullptr, nullptr}, live ? *live : TfLive{nullptr, nullptr});
+                       TfLossFuse{nullptr, 0.f, nullptr, nullptr, nullptr}, live ? *live : TfLive{nullptr, nullptr, nullptr, 0, 0});
     return TF_CHECK_LAUNCH();
 }
 
@@ -510,7 +527,7 @@ int tf_composite_forward_loss(int n_rays, const int* app_offset, const int* app_
     if (!fuse || !fuse->target || !fuse->grad || !fuse->loss || !fuse->state) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(composite_kernel, dim3((n_rays + 31) / 32), dim3(256), 0, (hipStream_t)stream, n_rays,
                        app_offset, app_count, app_w, rgb, acc, white_bg, rgb_map, rgb_pre, counters, n_shaded, *fuse,
-                       live ? *live : TfLive{nullptr, nullptr});
+                       live ? *live : TfLive{nullptr, nullptr, nullptr, 0, 0});
     return TF_CHECK_LAUNCH();
 }
 

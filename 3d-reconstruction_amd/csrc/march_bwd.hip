@@ -71,6 +71,7 @@ __global__ __launch_bounds__(64) void march_backward_kernel(const TfField F, con
     }
     const float bg = B.white_bg ? 1.f : 0.f;
     const int app_base = io.app_offset[r];
+    const int app_keep = io.app_count[r];       // (a right-sized app list holds only the entries that fit: TfMarchIO.seg_cap)
 
     // ---------------- pass 1: forward re-scan
     float T = 1.f;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(64) void march_backward_kernel(const TfField F, con
         float dw = 0.f;
         if (act) {
             float c3[3] = {0.f, 0.f, 0.f};
-            if (shade) {
+            if (shade && appcnt + prefix_popc(ms) < app_keep) {
                 const size_t s = (size_t)app_base + appcnt + prefix_popc(ms);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -158,19 +159,25 @@ __global__ __launch_bounds__(64) void march_backward_kernel(const TfField F, con
     // ---------------- pass 3: scatter
     if (B.ent_xyz) {
         // binned mode: hand every valid sample (xyz, dL/df) to tf_binned_scatter through the sharded entry list
+        const int shard = blockIdx.x & (TF_N_SHARDS - 1);
+        const int worst = ((gridDim.x + TF_N_SHARDS - 1) / TF_N_SHARDS) * N;
+        const int ent_cap = io.ent_seg_cap > 0 ? io.ent_seg_cap : worst;
         if (io.ent_offset) {      // the forward placed the entries (and wrote their coordinates) already
-            const size_t base = (size_t)io.ent_offset[r];
-            for (int k = lane; k < cnt; k += 64) B.ent_df[base + k] = sd[k];
+            const int base = io.ent_offset[r];
+            const int keep = max(0, min(cnt, (shard + 1) * ent_cap - base));       // what fitted the shard (TfMarchIO.ent_seg_cap)
+            for (int k = lane; k < keep; k += 64) B.ent_df[(size_t)base + k] = sd[k];
             return;
         }
-        const int shard = blockIdx.x & (TF_N_SHARDS - 1);
-        int base = 0;
+        int base = 0, keep = 0;
         if (lane == 0) {
-            const int seg_cap = ((gridDim.x + TF_N_SHARDS - 1) / TF_N_SHARDS) * N;
-            base = shard * seg_cap + atomicAdd(&io.counters[shard * TF_SHARD_STRIDE + 3], cnt);
+            const int a3 = atomicAdd(&io.counters[shard * TF_SHARD_STRIDE + 3], cnt);
+            keep = max(0, min(cnt, ent_cap - a3));
+            if (keep < cnt) atomicOr(&io.counters[TF_OVERFLOW_SLOT], 2);
+            base = shard * ent_cap + min(a3, ent_cap);
         }
         base = __shfl(base, 0, 64);
-        for (int k = lane; k < cnt; k += 64) {
+        keep = __shfl(keep, 0, 64);
+        for (int k = lane; k < keep; k += 64) {
             float p[3], u[3];
             sample_pos(ray, sample_z(F, ray, ztab, io.val_idx[vbase + k]), p);
             normalize(F, p, u);

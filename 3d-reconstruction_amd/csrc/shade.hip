@@ -94,7 +94,7 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
             int run = 0;
             for (int g = 0; g < TF_N_SHARDS; ++g) {
                 pre[g] = run;
-                run += src.counters[g * TF_SHARD_STRIDE];
+                run += min(src.counters[g * TF_SHARD_STRIDE], src.seg_cap);
             }
             pre[TF_N_SHARDS] = run;
         }

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
         int run = 0;
         for (int g = 0; g < TF_N_SHARDS; ++g) {
             pre[g] = run;
-            run += src.counters[g * TF_SHARD_STRIDE];
+            run += min(src.counters[g * TF_SHARD_STRIDE], src.seg_cap);
         }
         pre[TF_N_SHARDS] = run;
     }
@@ -799,7 +799,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
 // wrote its slab iff it owned samples, i.e. b * samples_per_wg < total.  One workgroup per 16x16 fragment tile (256
 // floats = 64 float4): thread (group g = tid>>6, lane) adds the slabs b = g, g+16, ... with 16-B loads, the sixteen
 // groups meet in LDS; the element's (row, column) is recovered from the tile's place in the slab (see WTiles).
-__global__ __launch_bounds__(1024) void wslab_reduce_kernel(const TfShade S, const int* __restrict__ counters,
+__global__ __launch_bounds__(1024) void wslab_reduce_kernel(const TfShade S, const int* __restrict__ counters, int seg_cap,
                                                             int n_wg, int ntw, const TfShadeGrads G) {
     constexpr int NG = 16;      // thread groups per tile: 256 slabs are 16 loads per thread, all in flight at once (with four
                                 // groups a thread walked 64 slabs four at a time: 15 us of load latency for 41 MB)
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(1024) void wslab_reduce_kernel(const TfShade S, con
     const int tid = threadIdx.x, grp = tid >> 6, lane = tid & 63;
     if (tid < 64) {
         static_assert(TF_N_SHARDS == 64, "one shard per lane");
-        int run = counters[tid * TF_SHARD_STRIDE];
+        int run = min(counters[tid * TF_SHARD_STRIDE], seg_cap);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) run += __shfl_xor(run, o, 64);
         if (tid == 0) {
@@ -862,7 +862,7 @@ __global__ __launch_bounds__(256) void app_direct_scatter_kernel(const TfShade S
         int run = 0;
         for (int g = 0; g < TF_N_SHARDS; ++g) {
             pre[g] = run;
-            run += (src.counters[g * TF_SHARD_STRIDE] + M - 1) / M;
+            run += (min(src.counters[g * TF_SHARD_STRIDE], src.seg_cap) + M - 1) / M;
         }
         pre[TF_N_SHARDS] = run;
     }
@@ -960,7 +960,7 @@ int tf_shade_backward(const TfShade* shade, const float* rays, int ndc, const in
     const int ntw = ntw_of(kpad16(shade->in_c) / 16);
     hipLaunchKernelGGL(fn, dim3(n_wg), dim3(512), bytes, (hipStream_t)stream, *shade, src, grad_rgb, *grads);
     hipLaunchKernelGGL(wslab_reduce_kernel, dim3((unsigned)(wslab_floats(*shade) / 256)), dim3(1024), 0, (hipStream_t)stream, *shade,
-                       counters, n_wg, ntw, *grads);
+                       counters, seg_cap, n_wg, ntw, *grads);
     if (grads->direct_scatter)
         hipLaunchKernelGGL(app_direct_scatter_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, *shade, src, *grads);
     return TF_CHECK_LAUNCH();

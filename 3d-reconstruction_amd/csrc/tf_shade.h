@@ -441,7 +441,7 @@ __device__ __forceinline__ bool locate_tile(const TileSrc& src, const int* pre /
         if (pre[mid] <= t) lo = mid; else hi = mid - 1;
     }
     const int lt = t - pre[lo];
-    const int cnt = src.counters[lo * TF_SHARD_STRIDE];
+    const int cnt = min(src.counters[lo * TF_SHARD_STRIDE], src.seg_cap);
     s0 = lo * src.seg_cap + lt * M;
     n = min(M, cnt - lt * M);
     return true;

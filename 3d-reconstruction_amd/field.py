@@ -209,9 +209,15 @@ class MLPRender(_MLPBase):
 class _Workspace:
     """Scratch for one forward call, carved from a single allocation (sizes follow tensorf_hip.h)."""
 
-    def __init__(self, R, N, device, save_valid, debug, binned=None, train_extra=None):
-        seg_cap = ((R + H.N_SHARDS - 1) // H.N_SHARDS) * N
-        cap = seg_cap * H.N_SHARDS
+    def __init__(self, R, N, device, save_valid, debug, binned=None, train_extra=None, caps=None):
+        worst = ((R + H.N_SHARDS - 1) // H.N_SHARDS) * N
+        # caps (training): entries per shard of the packed app list and of the density entry list (TfMarchIO.seg_cap /
+        # ent_seg_cap) — everything indexed by a packed position is sized by them, not by the worst case R * N: the saved
+        # rows alone are 2.2 KB per entry (9.4 GB at 4096 x 1039 for ~82 k entries in use)
+        seg_cap = worst if caps is None else max(64, min(worst, int(caps[0])))
+        ent_seg = worst if caps is None else max(64, min(worst, int(caps[1])))
+        cap, ecap = seg_cap * H.N_SHARDS, ent_seg * H.N_SHARDS
+        self.right_sized = caps is not None and (seg_cap < worst or ent_seg < worst)
         words = (N + 63) // 64
         n_ctr = H.N_SHARDS * H.SHARD_STRIDE
         # everything that must be zero when a forward starts sits in ONE block (one fill launch per step): the shard
@@ -231,11 +237,12 @@ class _Workspace:
                      ("xs", cap * kp_in, torch.float32), ("h1s", cap * fc, torch.float32), ("h2s", cap * fc, torch.float32)]
             if binned is not None:   # binned gradient scatter (csrc/bin.hip): entry lists + sort workspace
                 nkeys, kpe = max(binned[0], binned[1]), binned[2]
-                n_ints = 4 * (nkeys + 8) + kpe * cap // 128 + 64      # work items: <= pairs / chunk + keys, chunk >= 256
+                kpe_d, kpe_a = binned[6], binned[7]          # (key, group) pairs per entry of the density / appearance job
+                n_ints = 4 * (nkeys + 8) + max(kpe_a * cap, kpe_d * ecap) // 128 + 64      # work items: <= pairs / chunk + keys, chunk >= 256
                 # one sort workspace per job (density, appearance): both sorts run early, next to the shading kernels
-                spec += [("ent_xyz", cap * 3, torch.float32), ("ent_df", cap, torch.float32), ("ent_offset", R, torch.int32),
-                         ("binned", kpe * cap, torch.int32), ("bin_ints", n_ints, torch.int32),
-                         ("binned_app", kpe * cap, torch.int32), ("bin_ints_app", n_ints, torch.int32)]
+                spec += [("ent_xyz", ecap * 3, torch.float32), ("ent_df", ecap, torch.float32), ("ent_offset", R, torch.int32),
+                         ("binned", kpe_d * ecap, torch.int32), ("bin_ints", n_ints, torch.int32),
+                         ("binned_app", kpe_a * cap, torch.int32), ("bin_ints_app", n_ints, torch.int32)]
         if debug:
             spec += [("dbg_bbox", R * words * 2, torch.int32), ("dbg_valid", R * words * 2, torch.int32),
                      ("dbg_app", R * words * 2, torch.int32), ("dbg_z", R * N, torch.float32)]
@@ -249,10 +256,14 @@ class _Workspace:
         self.hist_density = self.zero_block[n_ctr:n_ctr + n_hist[0]]
         self.hist_app = self.zero_block[n_ctr + n_hist[0]:]
         self.R, self.N, self.seg_cap, self.cap, self.words = R, N, seg_cap, cap, words
+        self.ent_seg_cap, self.ent_cap, self.worst = ent_seg, ecap, worst
+        self.validated = not self.right_sized     # a right-sized workspace checks its first batch's demand synchronously
+        self.alpha_ref = None                     # the alpha mask its validation saw
         self.save_valid, self.debug, self.binned_cfg = save_valid, debug, binned
         self.bin_status = None             # sticky error word of the binned scatter (TfBinJob.status): the model's, set by
         if hasattr(self, "bin_ints"):      # TensorBase._workspace (zeroing one here would be a launch in every captured step)
             self.bin_ints_len, self.binned_len = self.bin_ints.numel(), self.binned.numel()
+            self.binned_app_len = self.binned_app.numel()
         self.busy = False
         self.owner = None      # weakref to the autograd ctx that holds this (training) workspace until its backward
         self.counters2d = self.counters.view(H.N_SHARDS, H.SHARD_STRIDE)
@@ -313,6 +324,7 @@ class TensorBase(nn.Module):
         # configurations and eager steps are better off with 512)
         self.bin_chunk_early = 256
         self._jitter_override = None   # tests: inject the stratified jitter instead of drawing it
+        self._sampling_override = None # retry_on_overflow: (jitter, z_table) device tensors of the step being repeated
         self._bg_override = None       # GraphedTrainStep: outcome of the random-background draw of tensorBase.py:380
         self._loss_fuse = None         # GraphedTrainStep: TfLossFuse — the compositing launch also forms the loss and its gradient
         self.static_jitter = None      # graph capture: device tensor (R,) the harness refills before every replay
@@ -323,7 +335,19 @@ class TensorBase(nn.Module):
         # eager autograd path returns None for those gradients too (one event wait on the forward per backward; single
         # process only).  FusedAdam gets the same behaviour from the device-side counts (`_live`, TfAdamJob.live).
         self.reference_none_grads = True
-        self._live = None              # device float[2]: density / shaded samples of the last training forward (TfLive.dev)
+        # Training workspaces are sized for (shaded, density) entries per ray with room to spare, not for the worst case
+        # R x N (9.9 GB at 4096 x 1039, of which 0.2 GB were ever touched).  A workspace's first batch is checked
+        # synchronously (and re-marched in a larger workspace if it does not fit); later batches are watched through the
+        # pinned sample counts: room is added before it runs out, and a batch that still overflows raises
+        # WorkspaceOverflow from backward() — see _hip.WorkspaceOverflow.  None: worst-case sizing (also used by
+        # multi-process groups, where the ranks would have to agree on every decision).
+        # (shaded, density) entries per ray; None = worst case for that list.  The density list is 40 B per entry and stays
+        # at its worst case (170 MB at 4096 x 1039): only the app list, whose entries carry 2.3 KB of saved rows, is cut
+        self.ws_entries_per_ray = (48, None)
+        self._caps = {}                # (R, N) -> [seg_cap, ent_seg_cap] learned from the batches seen so far
+        self._need_prev = {}           # (R, N) -> the previous batch's (shaded, density) demand per shard
+        self._live_host_override = None   # graph.GraphedTrainStep while capturing: (pinned ring, slot pointer, n_slots)
+        self._live = None              # device float[3]: density / shaded samples, overflow flag of the last training forward
         self._live_ring, self._live_i = None, 0     # pinned int32[2] + event per training forward in flight (TfLive.host)
         self._ws_cache = {}
         self._train_ws = {}
@@ -408,7 +432,7 @@ class TensorBase(nn.Module):
     # ---- which parameters a step without samples leaves without a gradient (TfAdamSeg.gate) ------------
     def _live_counts(self, dev):
         if self._live is None or self._live.device != torch.device(dev):
-            self._live = torch.ones(2, dtype=torch.float32, device=dev)
+            self._live = torch.tensor([1.0, 1.0, 0.0], dtype=torch.float32, device=dev)
         return self._live
 
     def _gate_of(self, name):
@@ -701,6 +725,8 @@ class TensorBase(nn.Module):
         (models/tensorBase.py:198-201).  NDC mode: `linspace(near, far, N)` built on the CPU, moved, then
         `rand_like` on the rays' device scaled by (far-near)/N (models/tensorBase.py:181-183)."""
         R = rays.shape[0]
+        if self._sampling_override is not None and is_train:      # a repeated step (WorkspaceOverflow): its own draws again
+            return self._sampling_override
         if not ndc_ray:
             if not is_train:
                 return None, None
@@ -759,7 +785,8 @@ class TensorBase(nn.Module):
                                   int(lib.tf_bin_keys_per_entry(mdl, C.byref(ca)))),
                               tile,
                               int(lib.tf_bin_nkeys(mdl, C.byref(g3), C.byref(cd), tile, self.bin_bucket, 1)),
-                              int(lib.tf_bin_nkeys(mdl, C.byref(g3), C.byref(ca), tile, self.bin_bucket, 1)))
+                              int(lib.tf_bin_nkeys(mdl, C.byref(g3), C.byref(ca), tile, self.bin_bucket, 1)),
+                              int(lib.tf_bin_keys_per_entry(mdl, C.byref(cd))), int(lib.tf_bin_keys_per_entry(mdl, C.byref(ca))))
                     if max(binned[0], binned[1]) <= H.BIN_MAX_KEYS:
                         break
                     binned = None
@@ -775,7 +802,8 @@ class TensorBase(nn.Module):
                 mlp_head = sh.head == H.HEAD_MLP
                 extra = (self._n_app_total(), wslab, (int(sh.in_c) + 15) // 16 * 16 if mlp_head else 0,
                          int(sh.feature_c) if mlp_head else 0)
-            ws = _Workspace(R, N, dev, save_valid, self._debug_masks, binned, extra)
+            ws = _Workspace(R, N, dev, save_valid, self._debug_masks, binned, extra,
+                            self._train_caps(R, N) if save_valid else None)
             if binned is not None:
                 if self._bin_status is None or self._bin_status.device != dev:
                     self._bin_status = torch.zeros(64, dtype=torch.int32, device=dev)
@@ -788,6 +816,64 @@ class TensorBase(nn.Module):
                 if len(pool) < 4:
                     pool.append(ws)
         return ws
+
+    # ---- right-sized training workspaces --------------------------------------------------------------------------
+    @staticmethod
+    def _round_cap(x):
+        return (int(x) + 255) // 256 * 256
+
+    def _train_caps(self, R, N):
+        """(entries per shard of the app list, of the density entry list) for a new training workspace, or None for the
+        worst case."""
+        if self.ws_entries_per_ray is None:
+            return None
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return None
+        c = self._caps.get((R, N))
+        if c is None:
+            rays_per_shard = (R + H.N_SHARDS - 1) // H.N_SHARDS
+            worst = rays_per_shard * N
+            per = self.ws_entries_per_ray
+            c = self._caps[(R, N)] = [worst if per[i] is None else self._round_cap(rays_per_shard * per[i]) for i in (0, 1)]
+        return c
+
+    def _grow_caps(self, R, N, need_app, need_ent, factor=1.3):
+        """Learns that a shard needed `need_app` / `need_ent` entries: future workspaces of this shape get `factor` x that
+        (never less than now), and the pooled ones that are too small are dropped."""
+        c = self._train_caps(R, N)
+        if c is None:
+            return
+        new = [max(c[0], self._round_cap(factor * need_app)), max(c[1], self._round_cap(factor * need_ent))]
+        if new != c:
+            self._caps[(R, N)] = new
+            for key in [k for k in self._train_ws if k[0] == R and k[1] == N]:
+                self._train_ws[key] = [w for w in self._train_ws[key] if w.seg_cap >= min(new[0], w.worst)
+                                       and w.ent_seg_cap >= min(new[1], w.worst)]
+
+    def retry_on_overflow(self, step_fn, tries=4):
+        """Runs `step_fn()` — one training step's forward + backward (+ whatever follows) — and, when its batch did not
+        fit the right-sized workspace (WorkspaceOverflow from backward(): the model has already made room), runs it
+        again with the SAME sampling jitter and background draw, so the repeated step is the step the reference's random
+        stream defined."""
+        try:
+            for attempt in range(tries):
+                try:
+                    return step_fn()
+                except H.WorkspaceOverflow as e:
+                    if attempt + 1 == tries:
+                        raise
+                    self._sampling_override, self._bg_override = (e.jitter, e.z_table), e.use_bg
+        finally:
+            self._sampling_override = self._bg_override = None
+
+    def workspace_bytes(self):
+        """Bytes held by this model's training workspaces (tests / DESIGN's footprint figures)."""
+        seen = {id(w): w for pool in self._train_ws.values() for w in pool}
+        last = self.last['ws'] if self.last is not None else None
+        if last is not None and last.save_valid:      # (in use, but no longer pooled: room was added for its successors)
+            seen[id(last)] = last
+        return sum(w.buf.numel() for w in seen.values())
 
     def _timed(self, name, fn, *args):
         """Runs one C-ABI launch; when `kernel_events` is a dict, brackets it with HIP events recorded on the
@@ -830,45 +916,66 @@ class TensorBase(nn.Module):
         plan = self._plan(save_valid, dev) if mask is None else None       # (also makes the host copy of the geometry)
         if plan is None and self._geom is None:
             self._field_desc([None, None, None])
-        ws = self._workspace(R, N, dev, save_valid)
-        if save_valid and self._sort_stream is not None and not torch.cuda.is_current_stream_capturing():
-            # a training forward whose backward never ran may have left its early sorts in flight on this workspace
-            torch.cuda.current_stream().wait_stream(self._sort_stream)
-        if plan is not None:    # cached descriptors; one pack launch when the weights changed, carrying the zero fill
-            field, shade, keep = plan.field, plan.shade, plan.keep
-            self._refresh_packed(plan, ws.zero_block)
-        else:
-            field = self._field_desc(den_masks)
-            self._zero_rode = False
-            shade, keep = self._shade_desc(app_masks, enc_mask, dev, train=save_valid, zero=ws.zero_block)
-            if not self._zero_rode:      # no weight copy was due (inference with unchanged weights): zero on its own
-                ws.zero_block.zero_()
-        st = _stream()
-
-        io = H.TfMarchIO()
-        io.rays, io.n_rays, io.n_samples, io.ndc = rays.data_ptr(), R, N, int(bool(ndc_ray))
-        io.jitter, io.z_table = H.ptr(jitter), H.ptr(ztab)
-        io.save_valid, io.t_stop = int(save_valid), float(self.t_stop)
+        capturing = torch.cuda.is_current_stream_capturing()
         # the two per-ray results are written straight into fresh tensors (no copy out of the workspace)
         out_rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
         out_depth = torch.empty(R, dtype=torch.float32, device=dev)
         # num_valid_samples (filled by the compositing kernel, which does not launch for an empty batch)
         out_n = (torch.empty if R > 0 else torch.zeros)((), dtype=torch.int64, device=dev) if self.count_samples else None
-        io.acc, io.depth = ws.acc.data_ptr(), out_depth.data_ptr()
-        io.app_offset, io.app_count, io.val_count = ws.app_offset.data_ptr(), ws.app_count.data_ptr(), ws.val_count.data_ptr()
-        io.counters = ws.counters.data_ptr()
-        io.app_ray, io.app_xyz, io.app_w = ws.app_ray.data_ptr(), ws.app_xyz.data_ptr(), ws.app_w.data_ptr()
-        early = bool(save_valid and ws.binned_cfg is not None and self.early_sort and after_march is not None)
-        if save_valid:
-            io.val_idx, io.val_feat = ws.val_idx.data_ptr(), ws.val_feat.data_ptr()
-            if early:       # the forward places the density entries of the backward's binned scatter (TfMarchIO.ent_xyz)
-                io.ent_xyz, io.ent_offset = ws.ent_xyz.data_ptr(), ws.ent_offset.data_ptr()
-        if ws.debug:
-            ws.dbg_app.zero_()
-            io.dbg_bbox_bits, io.dbg_valid_bits = ws.dbg_bbox.data_ptr(), ws.dbg_valid.data_ptr()
-            io.dbg_app_bits = ws.dbg_app.data_ptr()
-            io.dbg_z = ws.dbg_z.data_ptr()
-        self._timed("tf_march_forward", lib.tf_march_forward, C.byref(field), C.byref(io), st)
+        while True:
+            ws = self._workspace(R, N, dev, save_valid)
+            if save_valid and self._sort_stream is not None and not capturing:
+                # a training forward whose backward never ran may have left its early sorts in flight on this workspace
+                torch.cuda.current_stream().wait_stream(self._sort_stream)
+            if plan is not None:    # cached descriptors; one pack launch when the weights changed, carrying the zero fill
+                field, shade, keep = plan.field, plan.shade, plan.keep
+                self._refresh_packed(plan, ws.zero_block)
+            else:
+                field = self._field_desc(den_masks)
+                self._zero_rode = False
+                shade, keep = self._shade_desc(app_masks, enc_mask, dev, train=save_valid, zero=ws.zero_block)
+                if not self._zero_rode:      # no weight copy was due (inference with unchanged weights): zero on its own
+                    ws.zero_block.zero_()
+            st = _stream()
+
+            io = H.TfMarchIO()
+            io.rays, io.n_rays, io.n_samples, io.ndc = rays.data_ptr(), R, N, int(bool(ndc_ray))
+            io.jitter, io.z_table = H.ptr(jitter), H.ptr(ztab)
+            io.save_valid, io.t_stop = int(save_valid), float(self.t_stop)
+            io.seg_cap, io.ent_seg_cap = ws.seg_cap, ws.ent_seg_cap
+            io.acc, io.depth = ws.acc.data_ptr(), out_depth.data_ptr()
+            io.app_offset, io.app_count, io.val_count = ws.app_offset.data_ptr(), ws.app_count.data_ptr(), ws.val_count.data_ptr()
+            io.counters = ws.counters.data_ptr()
+            io.app_ray, io.app_xyz, io.app_w = ws.app_ray.data_ptr(), ws.app_xyz.data_ptr(), ws.app_w.data_ptr()
+            early = bool(save_valid and ws.binned_cfg is not None and self.early_sort and after_march is not None)
+            if save_valid:
+                io.val_idx, io.val_feat = ws.val_idx.data_ptr(), ws.val_feat.data_ptr()
+                if early:       # the forward places the density entries of the backward's binned scatter (TfMarchIO.ent_xyz)
+                    io.ent_xyz, io.ent_offset = ws.ent_xyz.data_ptr(), ws.ent_offset.data_ptr()
+            if ws.debug:
+                ws.dbg_app.zero_()
+                io.dbg_bbox_bits, io.dbg_valid_bits = ws.dbg_bbox.data_ptr(), ws.dbg_valid.data_ptr()
+                io.dbg_app_bits = ws.dbg_app.data_ptr()
+                io.dbg_z = ws.dbg_z.data_ptr()
+            self._timed("tf_march_forward", lib.tf_march_forward, C.byref(field), C.byref(io), st)
+            if ws.right_sized and ws.validated and ws.alpha_ref is not self.alphaMask and not capturing:
+                ws.validated = False      # a new alpha mask moves the sample counts by steps: check the next batch again
+            if ws.validated or capturing:
+                break
+            # first batch of a right-sized workspace: does it fit?  (one synchronous read, once per workspace)
+            ctr = ws.counters2d[:, :6].cpu()
+            need_app, need_ent = int(ctr[:, 0].max()), int(ctr[:, 1].max())      # per-shard demand (slot 1 >= the entries)
+            if int(ctr[0, H.OVERFLOW_SLOT]) == 0 and need_ent <= ws.ent_seg_cap:
+                ws.validated, ws.alpha_ref = True, self.alphaMask
+                if need_app > 0.7 * ws.seg_cap or need_ent > 0.7 * ws.ent_seg_cap:
+                    self._grow_caps(R, N, need_app, need_ent)        # (this workspace still serves; the next ones are larger)
+                break
+            self._grow_caps(R, N, need_app, need_ent)
+            ws.busy, ws.owner = False, None
+            pool = self._train_ws.get((R, N, str(dev), save_valid, self._debug_masks))
+            if pool is not None and ws in pool:
+                pool.remove(ws)
+            del ws
         # (the sorts are issued BEFORE the shading launch: issued behind it, tf_shade_forward follows the march kernel on the
         # same queue and runs alone — 116 us instead of 127 — but the first sort kernel then finds every CU slot taken and the
         # sorts finish behind the forward: 0.737 ms per captured step against 0.714)
@@ -886,9 +993,13 @@ class TensorBase(nn.Module):
         if save_valid:          # the step's sample counts: device words for FusedAdam's gates, pinned words for autograd
             live = H.TfLive()
             live.dev = self._live_counts(dev).data_ptr()
-            live_slot = self._live_slot()
-            if live_slot is not None:
-                live.host = live_slot[0].data_ptr()
+            if self._live_host_override is not None:      # GraphedTrainStep: a ring of pinned slots, the slot staged per step
+                ring, slot_ptr, n_slots = self._live_host_override
+                live.host, live.slot, live.n_slots = ring.data_ptr(), slot_ptr, n_slots
+            else:
+                live_slot = self._live_slot(ws.right_sized)
+                if live_slot is not None:
+                    live.host = live_slot[0].data_ptr()
         if fuse is not None:
             self._timed("tf_composite_forward", lib.tf_composite_forward_loss, R, ws.app_offset.data_ptr(),
                         ws.app_count.data_ptr(), ws.app_w.data_ptr(), ws.rgb.data_ptr(), ws.acc.data_ptr(), int(use_bg),
@@ -909,17 +1020,18 @@ class TensorBase(nn.Module):
         self.last = ctx
         return ctx
 
-    def _live_slot(self):
-        """(pinned int32[2], event) for this training forward's sample counts, or None when nobody will read them on the
-        host: inside a graph capture, with `reference_none_grads` off, or in a multi-process group (a rank cannot drop a
-        gradient the other ranks exchange; there the device-side counts are summed with the gradients, parallel.py)."""
-        if not self.reference_none_grads or torch.cuda.is_current_stream_capturing():
+    def _live_slot(self, right_sized=False):
+        """(pinned int32[4], event) for this training forward's sample counts and overflow flag, or None when nobody will
+        read them on the host: inside a graph capture, with `reference_none_grads` off and a worst-case workspace, or in a
+        multi-process group (a rank cannot drop a gradient the other ranks exchange; there the device-side counts are
+        summed with the gradients, parallel.py)."""
+        if torch.cuda.is_current_stream_capturing() or not (self.reference_none_grads or right_sized):
             return None
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             return None
         if self._live_ring is None:
-            self._live_ring = [(torch.zeros(2, dtype=torch.int32).pin_memory(), torch.cuda.Event()) for _ in range(8)]
+            self._live_ring = [(torch.zeros(4, dtype=torch.int32).pin_memory(), torch.cuda.Event()) for _ in range(8)]
         slot = self._live_ring[self._live_i % len(self._live_ring)]
         self._live_i += 1
         return slot

@@ -24,6 +24,7 @@ draw per global batch, shared by the ranks — see `bg_seed`).  Results of EARLI
 model (`rgb`, the loss) must not be alive when the step is captured: they keep autograd's AccumulateGrad nodes bound
 to the stream they ran on, the capture would record a dependency on that stream and HIP fails in
 `hipStreamEndCapture` (torch warns "AccumulateGrad node's stream does not match")."""
+import collections
 import ctypes as C
 
 import torch
@@ -55,7 +56,15 @@ class GraphedTrainStep:
         dev = next(model.parameters()).device
         self.rays = torch.zeros(batch, 6, device=dev)
         self.target = torch.zeros(batch, 3, device=dev)
-        self.jitter = torch.zeros(batch, device=dev)
+        # [0, batch): the step's sampling jitter; [batch]: the slot of the pinned report ring this step writes its sample
+        # counts / overflow flag to (TfLive.slot) — both staged by one launch in front of every replay
+        self._jitter_all = torch.zeros(batch + 1, device=dev)
+        self.jitter = self._jitter_all[:batch]
+        self._n_slots = 32
+        self._ring = torch.zeros(self._n_slots, 4, dtype=torch.int32).pin_memory()
+        self._ring_np = self._ring.numpy()
+        self._pending = collections.deque()     # steps whose report has not been read yet
+        self._step_no = 0
         self.loss = torch.zeros((), device=dev)
         self._grad_rgb = torch.zeros(batch, 3, device=dev)
         self._loss_state = torch.zeros(2, device=dev)      # tf_composite_forward_loss: running sum + arrival counter
@@ -115,6 +124,7 @@ class GraphedTrainStep:
         # (tf_composite_forward_loss): no launch of their own between the forward and the backward
         model._loss_fuse = self._fuse(1.0 / self._world if self.split else 1.0)
         model._grad_store = self._store()
+        model._live_host_override = self._live_override()
         try:
             rgb, _, _ = model(self.rays, self.mask, white_bg=self.white_bg, is_train=True, ndc_ray=self.ndc,
                               N_samples=self.n_samples)
@@ -123,10 +133,15 @@ class GraphedTrainStep:
             rgb.backward(self._grad_rgb)
         finally:
             model.count_samples = keep
-            model._loss_fuse = model._grad_store = None
+            model._loss_fuse = model._grad_store = model._live_host_override = None
 
     def _store(self):
         return self._gstore if hasattr(self.opt, "consume_grads") else None
+
+    def _live_override(self):
+        """Where this step's compositing launch reports its sample counts and overflow flag: slot `jitter[batch]` of the
+        pinned ring (a captured launch cannot change its arguments; the slot number is staged with the jitter)."""
+        return (self._ring, self._jitter_all.data_ptr() + 4 * self.rays.shape[0], self._n_slots)
 
     def _fuse(self, grad_scale):
         """TfLossFuse of this step's static buffers (target, gradient, loss, the kernel's two state words)."""
@@ -216,6 +231,7 @@ class GraphedTrainStep:
         hook, model._density_grads_ready = getattr(model, "_density_grads_ready", None), None   # no collective in a capture
         model._loss_fuse = self._fuse(1.0 / self._world)
         model._grad_store = self._store()
+        model._live_host_override = self._live_override()
         try:
             with torch.no_grad():
                 c = model._run_forward(self.rays, self.mask, self.white_bg, True, self.ndc, self.n_samples, save_valid=True,
@@ -227,7 +243,7 @@ class GraphedTrainStep:
         finally:
             model.count_samples = keep
             model._density_grads_ready = hook
-            model._loss_fuse = model._grad_store = None
+            model._loss_fuse = model._grad_store = model._live_host_override = None
         for n, p in named:
             p.grad = grads[n]
         self._ctx = (c, named)
@@ -293,13 +309,13 @@ class GraphedTrainStep:
         pinned buffer the staging launch reads in place.  The buffers go round a ring: a slot is rewritten only after the
         launch that read it has run (the host issues replays far ahead of the GPU)."""
         R = self.rays.shape[0]
-        if self._jit_ring is None:
-            self._jit_ring = [[torch.empty(R, 1).pin_memory(), None] for _ in range(32)]
+        if self._jit_ring is None:      # R jitter values + the report slot of the step (_live_override)
+            self._jit_ring = [[torch.zeros(R + 1).pin_memory(), None] for _ in range(32)]
         slot = self._jit_ring[self._jit_i % len(self._jit_ring)]
         self._jit_i += 1
         if slot[1] is not None:
             slot[1].synchronize()
-        torch.rand(R, 1, out=slot[0])
+        torch.rand(R, 1, out=slot[0][:R].view(R, 1))
         return slot
 
     def _stage(self, rays, target, ids, slot):
@@ -313,7 +329,7 @@ class GraphedTrainStep:
             # allrays[ray_idx], allrgbs[ray_idx] (train.py:297-298) straight into the static buffers
             H.check(H.lib().tf_gather_batch_staged(rays.data_ptr(), target.data_ptr(), rays.shape[0], ids.contiguous().data_ptr(),
                                                    R, self.rays.data_ptr(), self.target.data_ptr(), slot[0].data_ptr(),
-                                                   self.jitter.data_ptr(), R, C.byref(job) if job is not None else None,
+                                                   self._jitter_all.data_ptr(), R + 1, C.byref(job) if job is not None else None,
                                                    _stream()), "tf_gather_batch_staged")
         else:
             if ids is None:
@@ -322,8 +338,8 @@ class GraphedTrainStep:
             else:
                 torch.index_select(rays, 0, ids, out=self.rays)
                 torch.index_select(target, 0, ids, out=self.target)
-            H.check(H.lib().tf_gather_batch_staged(None, None, 0, None, 0, None, None, slot[0].data_ptr(), self.jitter.data_ptr(),
-                                                   R, C.byref(job) if job is not None else None, _stream()),
+            H.check(H.lib().tf_gather_batch_staged(None, None, 0, None, 0, None, None, slot[0].data_ptr(), self._jitter_all.data_ptr(),
+                                                   R + 1, C.byref(job) if job is not None else None, _stream()),
                     "tf_gather_batch_staged")
         if slot[1] is None:
             slot[1] = torch.cuda.Event()
@@ -331,26 +347,80 @@ class GraphedTrainStep:
 
     def step(self, rays, target, ids=None):
         """One optimisation step on (rays, target) — or on rows `ids` of them; returns the (device) loss tensor."""
+        lost = self._poll()
+        if lost:
+            self._recover(lost)
         if self._graphs and not self._same(self._signature(), self._captured_for):
             # the model changed under the graph (updateAlphaMask / shrink / upsample_volume_grid replace the mask and the
             # parameters, train.py:300-311): the captured pointers are stale -> warm up and capture again.  (Checked before
             # the staging launch, which runs the captured forward's weight-pack job.)
-            self._graphs = {}
-            self._packjobs = {}
-            self._items = {}
-            self.graph = self.graph_opt = None
-            self._warm = 1
+            self._drop_graphs()
         slot = self._draw_jitter()
         # random-background draw of tensorBase.py:380, taken after the jitter draw like the reference's forward does
-        self._bg = True if self.white_bg else bool(torch.rand((1,)) < 0.5)
+        bg = True if self.white_bg else bool(torch.rand((1,)) < 0.5)
         if self._bg_gen is not None:
-            self._bg = bool(torch.rand((1,), generator=self._bg_gen) < 0.5)
+            bg = bool(torch.rand((1,), generator=self._bg_gen) < 0.5)
+        return self._submit(rays, target, ids, slot, bg)
+
+    def _drop_graphs(self):
+        self._graphs = {}
+        self._packjobs = {}
+        self._items = {}
+        self.graph = self.graph_opt = None
+        self._warm = 1
+
+    def _submit(self, rays, target, ids, slot, bg):
+        """Stages and runs one step whose random draws (`slot`: pinned jitter, `bg`) are already made."""
+        if len(self._pending) >= self._n_slots - 2:        # a report slot is reused only after its report has been read
+            self._pending[0][6].synchronize()
+            lost = self._poll()
+            if lost:
+                self._recover(lost)
+        report = self._step_no % self._n_slots
+        self._step_no += 1
+        slot[0][self.rays.shape[0]] = float(report)
+        seen = int(self._ring_np[report, 3])
+        self._bg = bg
         self._stage(rays, target, ids, slot)
         self.model._bg_override = self._bg
         try:
-            return self._step()
+            loss = self._step()
         finally:
             self.model._bg_override = None
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending.append((report, seen, rays, target, ids, (slot, bg), ev))
+        return loss
+
+    def _poll(self):
+        """Reads the reports that have come in (pinned memory, no synchronisation): returns the steps whose right-sized
+        workspace overflowed — their gradients were incomplete and FusedAdam's gate left the parameters alone."""
+        lost = []
+        while self._pending:
+            rec = self._pending[0]
+            h = self._ring_np[rec[0]]
+            if int(h[3]) == rec[1]:
+                break                                   # this step has not reported yet (nor have the later ones)
+            self._pending.popleft()
+            if int(h[2]) != 0:
+                lost.append((rec, int(h[0]), int(h[1])))
+        return lost
+
+    def _recover(self, lost):
+        """Steps that overflowed their workspace are run again, in order, after the workspace has grown (steps that were
+        enqueued behind them and fitted have been applied meanwhile: the batches commute up to that reordering)."""
+        torch.cuda.synchronize()
+        lost += self._poll()
+        assert not self._pending
+        ws = self.model.last['ws'] if self.model.last is not None else None
+        if ws is not None:
+            per = 1.15 / H.N_SHARDS
+            self.model._grow_caps(ws.R, ws.N, max(l[2] for l in lost) * per, max(l[1] for l in lost) * per)
+        self._drop_graphs()
+        self.overflow_reruns = getattr(self, "overflow_reruns", 0) + len(lost)
+        for rec, _, _ in lost:
+            _, _, rays, target, ids, (slot, bg), _ = rec
+            self._submit(rays, target, ids, slot, bg)
 
     def _step(self):
         if hasattr(self.opt, "sync_lr") and self.opt._lr_dev is not None:

@@ -123,33 +123,39 @@ def train(tensorf, allrays, allrgbs, cfg=None, device="cuda", rank=0, world=1, l
             loss = gs.step(allrays, allrgbs, ids)
         else:
             rays_train, rgb_train = allrays[ids], allrgbs[ids].to(device)
-            rgb_map, _, depth_map, _, _, n = OctreeRender_trilinear_fast(
-                rays_train, tensorf, mask, chunk=batch, N_samples=nSamples, white_bg=c["white_bg"], ndc_ray=c["ndc_ray"],
-                device=device, is_train=True)
-            loss = torch.mean((rgb_map - rgb_train) ** 2)
-            if hasattr(opt, "set_regularizer_activity"):    # (FusedAdam: these terms open the factor tensors' gates)
-                opt.set_regularizer_activity(use_ortho > 0, l1_w > 0, tv_d > 0, tv_a > 0)
-            if c.get("fused_regularizers", True) and fused_supported(tensorf):
-                # train.py:340-371 in one pass over the factor tensors (tf_regularizers): the terms do not depend on the
-                # rays, so their gradient is added after the data gradients have been reduced across ranks
-                opt.zero_grad()
-                loss.backward()
-                parallel.finish_gradient_exchange(tensorf)
-                if max(use_ortho, l1_w, tv_d, tv_a) > 0:
-                    add_regularizer_grads_(tensorf, use_ortho, l1_w, max(tv_d, 0.0), max(tv_a, 0.0))
-            else:
-                total = loss
-                if use_ortho > 0:
-                    total = total + use_ortho * tensorf.vector_comp_diffs()
-                if l1_w > 0:
-                    total = total + l1_w * tensorf.density_L1()
-                if tv_d > 0:
-                    total = total + tensorf.TV_loss_density(tvreg) * tv_d
-                if tv_a > 0:
-                    total = total + tensorf.TV_loss_app(tvreg) * tv_a
-                opt.zero_grad()
-                total.backward()
-                parallel.allreduce_gradients(tensorf)
+
+            def one_step():
+                rgb_map, _, depth_map, _, _, n = OctreeRender_trilinear_fast(
+                    rays_train, tensorf, mask, chunk=batch, N_samples=nSamples, white_bg=c["white_bg"], ndc_ray=c["ndc_ray"],
+                    device=device, is_train=True)
+                loss = torch.mean((rgb_map - rgb_train) ** 2)
+                if hasattr(opt, "set_regularizer_activity"):    # (FusedAdam: these terms open the factor tensors' gates)
+                    opt.set_regularizer_activity(use_ortho > 0, l1_w > 0, tv_d > 0, tv_a > 0)
+                if c.get("fused_regularizers", True) and fused_supported(tensorf):
+                    # train.py:340-371 in one pass over the factor tensors (tf_regularizers): the terms do not depend on the
+                    # rays, so their gradient is added after the data gradients have been reduced across ranks
+                    opt.zero_grad()
+                    loss.backward()
+                    parallel.finish_gradient_exchange(tensorf)
+                    if max(use_ortho, l1_w, tv_d, tv_a) > 0:
+                        add_regularizer_grads_(tensorf, use_ortho, l1_w, max(tv_d, 0.0), max(tv_a, 0.0))
+                else:
+                    total = loss
+                    if use_ortho > 0:
+                        total = total + use_ortho * tensorf.vector_comp_diffs()
+                    if l1_w > 0:
+                        total = total + l1_w * tensorf.density_L1()
+                    if tv_d > 0:
+                        total = total + tensorf.TV_loss_density(tvreg) * tv_d
+                    if tv_a > 0:
+                        total = total + tensorf.TV_loss_app(tvreg) * tv_a
+                    opt.zero_grad()
+                    total.backward()
+                    parallel.allreduce_gradients(tensorf)
+                return loss
+
+            # (a batch that outgrows the right-sized workspace is repeated with its own jitter: field.retry_on_overflow)
+            loss = tensorf.retry_on_overflow(one_step) if hasattr(tensorf, "retry_on_overflow") else one_step()
             opt.step()
         for g in opt.param_groups:
             g["lr"] = g["lr"] * lr_factor

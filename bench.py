@@ -371,11 +371,16 @@ def main():
     def train_step(i):
         ids = parallel.shard_ids(perm[i], rank, world)
         rays_train, rgb_train = rays[ids], targets[ids]
-        rgb_map, _, depth_map, _, _, n = renderer(rays_train, model, None, chunk=B, N_samples=n_samples, white_bg=white,
-                                                   ndc_ray=ndc, device=dev, is_train=True)
-        loss = torch.mean((rgb_map - rgb_train) ** 2)
-        opt.zero_grad()
-        loss.backward()
+
+        def fwd_bwd():
+            rgb_map, _, depth_map, _, _, n = renderer(rays_train, model, None, chunk=B, N_samples=n_samples, white_bg=white,
+                                                       ndc_ray=ndc, device=dev, is_train=True)
+            loss = torch.mean((rgb_map - rgb_train) ** 2)
+            opt.zero_grad()
+            loss.backward()
+            return loss
+
+        loss = model.retry_on_overflow(fwd_bwd)       # (a batch that outgrows the right-sized workspace is repeated)
         parallel.finish_gradient_exchange(model)      # (its density bucket left during the backward)
         ev = model.kernel_events
         if ev is not None:
@@ -547,7 +552,8 @@ def main():
                                  if use_graph else "eager",
                        "optimizer": "torch.optim.Adam(fused)" if args.torch_adam else "Adam, one launch (tf_adam_step)",
                        "inputs": "host, gathered on the CPU + H2D per step" if args.host_inputs else "resident in HBM",
-                       "eager_ms_per_step": eager_ms, "host_issue_ms_per_step": host_issue / k * 1e3},
+                       "eager_ms_per_step": eager_ms, "host_issue_ms_per_step": host_issue / k * 1e3,
+                       "training_workspace_GiB": round(model.workspace_bytes() / 2 ** 30, 3)},
             "roofline": roof,
             "step_hbm_roofline": step_hbm,
             "kernels": {n: {"avg_ms": round(v["avg_ms"], 5), "launches_per_step": round(v["launches_per_step"], 2),

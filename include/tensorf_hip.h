@@ -31,13 +31,19 @@ typedef void* tf_stream_t; /* hipStream_t */
 /* The packed app list is written through TF_N_SHARDS independent reservation counters (one per
  * 128-B line, TF_SHARD_STRIDE ints apart) so that one atomic per ray never serialises on a single
  * word.  Shard g owns packed entries [g*seg_cap, g*seg_cap + counters[g*TF_SHARD_STRIDE]) with
- * seg_cap = ceil(R / TF_N_SHARDS) * N.  counters[g*STRIDE+1] / [+2] accumulate the number of density
- * samples / in-bbox samples (statistics for the roofline report). */
+ * seg_cap = TfMarchIO.seg_cap entries per shard (0: the worst case ceil(R / TF_N_SHARDS) * N).  counters[g*STRIDE+1] / [+2]
+ * accumulate the number of density samples / in-bbox samples (statistics for the roofline report).
+ * Right-sized lists: a ray whose samples do not fit its shard's remaining room writes the part that fits (every position
+ * stays inside the buffers), the counters keep counting the DEMAND (so the host knows how much room the batch needs),
+ * every reader takes min(counter, seg_cap), and counters[TF_OVERFLOW_SLOT] is set: the step's results are then
+ * incomplete — tf_composite_forward publishes the flag (TfLive), tf_adam_step refuses to update, the host re-runs the
+ * batch with a larger workspace. */
 #define TF_N_SHARDS 64
 #define TF_SHARD_STRIDE 32
 #define TF_MAX_SAMPLES 8192   /* samples per ray handled by one LDS queue */
 #define TF_TILE 64            /* shaded samples per shading tile */
 #define TF_TICKET_SLOT 4      /* counters[4]: tile ticket of tf_shade_forward (zeroed with the counters) */
+#define TF_OVERFLOW_SLOT 5    /* counters[5]: non-zero once a packed list (bit 0: shaded samples, bit 1: density entries) ran full */
 
 enum { TF_MODEL_VM = 0, TF_MODEL_CP = 1 };
 enum { TF_ACT_SOFTPLUS = 0, TF_ACT_RELU = 1 };
@@ -117,6 +123,9 @@ typedef struct TfMarchIO {
     float* ent_xyz;        /* (cap,3) or NULL */
     int* ent_offset;       /* (R) first density entry of the ray */
     float* dbg_z;          /* tests (optional): (R, n_samples) the sample positions z of tensorBase.py:198-203 / :181-183 */
+    int seg_cap;           /* entries per shard of the packed app list (app_ray / app_xyz / app_w and everything indexed like
+                            * them: colours, saved rows); 0 = worst case ceil(R / TF_N_SHARDS) * N */
+    int ent_seg_cap;       /* the same for the density entry list (ent_xyz / ent_df, counter slot 3); 0 = worst case */
 } TfMarchIO;
 
 /* One positional-encoding block of the MLP input (mlp.py:8-13, 41-66, 84-103, 126-153). */
@@ -210,10 +219,15 @@ int tf_shade_forward(const TfShade* shade, const float* rays, int ndc, const int
  * number of density samples (ray_valid.sum(), tensorBase.py:359), dev[1] = number of shaded samples (app_mask.sum(),
  * :370) as floats in device memory; host[0..1] the same as ints in PINNED host memory (read them after an event
  * recorded behind this launch: the autograd binding returns None gradients for the tensors the reference's graph would
- * not contain).  Either pointer may be NULL. */
+ * not contain).  dev[2] / host[2]: non-zero when a right-sized list overflowed (TF_OVERFLOW_SLOT): the step is incomplete.
+ * Either pointer may be NULL. */
 typedef struct TfLive {
-    float* dev;
-    int* host;
+    float* dev;            /* 3 floats: density samples, shaded samples, overflow flags (counters[TF_OVERFLOW_SLOT]) */
+    int* host;             /* n_slots x 4 ints in pinned host memory: the same three (+ 1 spare) per slot */
+    const float* slot;     /* NULL (slot 0), or a device float holding the slot this step reports to — a captured launch
+                            * cannot change its arguments, the caller changes *slot (graph.GraphedTrainStep stages it) */
+    int n_slots;
+    int pad_;
 } TfLive;
 int tf_composite_forward(int n_rays, const int* app_offset, const int* app_count, const float* app_w,
                          const float* rgb, const float* acc, int white_bg, float* rgb_map, float* rgb_pre,
@@ -470,7 +484,8 @@ typedef struct TfAdamJob {
     unsigned int* touched;    /* NULL, or one word per workgroup (chunk of TF_ADAM_CHUNK elements), zero when the
                                * moments are created: bit set = that 256-float piece has had a non-zero gradient;
                                * pieces whose bit is clear have zero moments, which are then not read */
-    const float* live;        /* NULL (no gates), or 2 device floats: density samples, shaded samples of this step */
+    const float* live;        /* NULL (no gates), or 3 device floats: density samples, shaded samples of this step, and the
+                               * overflow flag of its right-sized lists (non-zero: NO segment is updated) */
     const float* reg_active;  /* NULL, or 4 device floats: non-zero = that regulariser term is part of the loss */
     unsigned int skip_mask;   /* bit s: segment s has no gradient this step */
     int pad_;

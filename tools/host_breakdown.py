@@ -7,8 +7,9 @@ import recon_amd
 sys.argv = [sys.argv[0]]
 import bench
 dev = torch.device("cuda", 0)
-model, rays, targets, n_samples, reso = bench.build_scene(recon_amd, dev, 300, 3)
+model, rays, targets, n_samples, reso, _ndc, _white = bench.build_scene(recon_amd, dev, bench.parse(), 0)
 model.lazy_sample_count = True
+model.reference_none_grads = bool(int(os.environ.get("NONE_GRADS", "1")))
 opt = recon_amd.FusedAdam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
 perm = torch.randperm(rays.shape[0], device=dev)
 import gc; gc.collect(); gc.freeze()
