@@ -39,6 +39,7 @@ class FusedAdam(torch.optim.Optimizer):
         # True: step() also returns every gradient it consumed to zero (TfAdamJob.clear_grads) — zero_grad() folded into the
         # update for callers that accumulate the next step's gradients into the same buffer (graph.GraphedTrainStep)
         self.consume_grads = False
+        self.kernel_events = None   # bench.py: dict name -> [(start, end)] HIP events around the launch
 
     def _params(self):
         return [(gi, p) for gi, g in enumerate(self.param_groups) for p in g['params'] if p.requires_grad]
@@ -205,7 +206,15 @@ class FusedAdam(torch.optim.Optimizer):
                 rec[3] = [base, gp]
             job.skip_mask = skip
             job.clear_grads = int(bool(self.consume_grads))
-            H.check(lib.tf_adam_step(C.byref(job), st), "tf_adam_step")
+            ev = self.kernel_events
+            if ev is not None and not torch.cuda.is_current_stream_capturing():     # bench: HIP events around the launch
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                H.check(lib.tf_adam_step(C.byref(job), st), "tf_adam_step")
+                b.record()
+                ev.setdefault("tf_adam_step", []).append((a, b))
+            else:
+                H.check(lib.tf_adam_step(C.byref(job), st), "tf_adam_step")
         # the kernel wrote the parameters behind autograd's back: caches keyed on ._version (packed weight copies,
         # field.py) must see the change
         torch.autograd.graph.increment_version([p for _, p in ps])
