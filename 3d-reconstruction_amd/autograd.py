@@ -99,7 +99,7 @@ def _bin_job(model, ws, part, factors, grid, stage, fgrads=None, grad=None, grad
     j.stage = stage
     # capacities the kernels check every position against (TfBinJob.status collects violations)
     j.binned_cap = ws.binned_app_len if app else ws.binned_len
-    j.items_cap = ws.bin_ints_len - (2 * (nmax + 8) + nkeys + 1)      # ints behind chunk_off[nkeys + 1]
+    j.items_cap = (ws.bin_ints_len - (2 * (nmax + 8) + nkeys + 1) - 4) // 4      # int4 items behind chunk_off[nkeys + 1] (16-B aligned)
     j.status = ws.bin_status.data_ptr()
     return j
 
@@ -110,6 +110,12 @@ def _early_sort(model, ws, field, shade, named):
     (three small, latency-bound kernels each) are issued on a second stream here and run next to the shading
     kernels.  The backward joins before its first scatter.  Works the same inside a hipGraph capture."""
     main = torch.cuda.current_stream()
+    if getattr(model, "_sort_inline", False):     # bench.py's per-kernel timing pass: same launches, no overlap
+        lib = H.lib()
+        model._timed("tf_binned_sort_pair", lib.tf_binned_sort_pair,
+                     C.byref(_bin_job(model, ws, "density", field.density, field.grid, 1)),
+                     C.byref(_bin_job(model, ws, "app", shade.app, field.grid, 1)), _stream())
+        return main, _grad_buffers(named, 0, getattr(model, "_grad_store", None))
     if model._sort_stream is None:
         model._sort_stream = torch.cuda.Stream(device=main.device, priority=-1)   # its few workgroups go first
     side = model._sort_stream

@@ -14,69 +14,77 @@ namespace {
 constexpr int kChunk = TF_ADAM_CHUNK;   // elements per workgroup
 static_assert(TF_ADAM_CHUNK == 8192, "the touched word holds 4 waves x 8 rounds of 256 floats");
 
-// Is segment s updated by this launch?  (TfAdamJob: host skip mask, sample-count gate, regulariser flags.)
-__device__ __forceinline__ bool seg_open(const TfAdamJob& J, int s) {
+// The launch's gate words, read ONCE and together (they are the same for every workgroup: scalar loads, one round trip —
+// read one after the other behind branches they were two more L2 latencies in front of every workgroup's first load).
+struct Gates {
+    float live0, live1, over;      // density samples, shaded samples, overflow flag of the step (TfLive)
+    float reg[4];                  // regulariser activity
+};
+__device__ __forceinline__ Gates load_gates(const TfAdamJob& J) {
+    Gates g;
+    g.live0 = J.live ? J.live[0] : 1.f;
+    g.live1 = J.live ? J.live[1] : 1.f;
+    g.over = J.live ? J.live[2] : 0.f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) g.reg[b] = J.reg_active ? J.reg_active[b] : 0.f;
+    return g;
+}
+// Is segment s updated by this launch?  (TfAdamJob: host skip mask, overflow, sample-count gate, regulariser flags.)
+__device__ __forceinline__ bool seg_open(const TfAdamJob& J, const Gates& g, int s) {
     if ((J.skip_mask >> s) & 1u) return false;
-    if (J.live && J.live[2] != 0.f) return false;      // a right-sized list of this step ran full: its gradients are incomplete
+    if (g.over != 0.f) return false;      // a right-sized list of this step ran full: its gradients are incomplete
     const int gate = J.seg[s].gate;
     const int cnt = gate & 3;
-    if (!cnt || !J.live) return true;
-    if (J.live[cnt - 1] != 0.f) return true;
-    if (J.reg_active) {
+    if (!cnt) return true;
+    if ((cnt == 1 ? g.live0 : g.live1) != 0.f) return true;
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
-            if (((gate >> (4 + b)) & 1) && J.reg_active[b] != 0.f) return true;
-    }
+    for (int b = 0; b < 4; ++b)
+        if (((gate >> (4 + b)) & 1) && g.reg[b] != 0.f) return true;
     return false;
 }
 
 // Last workgroup of the launch: advance the counts of the updated segments, re-arm the arrival counter.
-__device__ __forceinline__ void arrive(const TfAdamJob& J) {
+__device__ __forceinline__ void arrive(const TfAdamJob& J, const Gates& g) {
     if (atomicAdd(J.arrivals, 1u) == gridDim.x - 1) {
         for (int s = 0; s < J.n_seg; ++s)
-            if (seg_open(J, s)) J.step[s] = J.step[s] + 1.f;
+            if (seg_open(J, g, s)) J.step[s] = J.step[s] + 1.f;
         *J.arrivals = 0u;
     }
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(const TfAdamJob J) {
     __shared__ float s_hyp[2];
-    __shared__ int s_seg;
     const int tid = threadIdx.x;
-    if (tid == 0) {
-        int s = 0;
-        while (s + 1 < J.n_seg && (int)blockIdx.x >= J.chunk_end[s]) ++s;
-        const bool open = seg_open(J, s);
-        s_seg = open ? s : -1;
-        const double t = (double)J.step[s] + 1.0;    // step[s] counts the segment's completed updates; this is number t
-        const double bc1 = 1.0 - pow(J.beta1, t), bc2 = 1.0 - pow(J.beta2, t);
-        s_hyp[0] = (float)((double)J.lrs[J.seg[s].group] / (double)(float)bc1);   // step size
-        s_hyp[1] = (float)sqrt(bc2);
-    }
-    __shared__ int s_seg_any;
-    if (tid == 0) {
-        int s = 0;
-        while (s + 1 < J.n_seg && (int)blockIdx.x >= J.chunk_end[s]) ++s;
-        s_seg_any = s;
-    }
-    __syncthreads();
-    if (s_seg < 0) {         // a parameter without a gradient this step: untouched, like torch.optim.Adam's `grad is None`
+    // segment and gate of this workgroup: wave-uniform arithmetic on kernel arguments and a handful of scalar loads, done
+    // by every thread (no LDS hand-over in front of the first memory request)
+    const Gates gates = load_gates(J);
+    int seg = 0;
+    while (seg + 1 < J.n_seg && (int)blockIdx.x >= J.chunk_end[seg]) ++seg;
+    const bool open = seg_open(J, gates, seg);
+    if (!open) {             // a parameter without a gradient this step: untouched, like torch.optim.Adam's `grad is None`
         // ... but a caller that accumulates the next step into the same buffer (clear_grads) must get it back clean: a
         // step whose lists overflowed leaves INCOMPLETE non-zero gradients behind, which are dropped here
-        if (J.clear_grads && !((J.skip_mask >> s_seg_any) & 1u)) {
-            const TfAdamSeg& sc = J.seg[s_seg_any];
-            const long long c0 = (long long)((int)blockIdx.x - (s_seg_any ? J.chunk_end[s_seg_any - 1] : 0)) * kChunk;
+        if (J.clear_grads && !((J.skip_mask >> seg) & 1u)) {
+            const TfAdamSeg& sc = J.seg[seg];
+            const long long c0 = (long long)((int)blockIdx.x - (seg ? J.chunk_end[seg - 1] : 0)) * kChunk;
             const long long n = sc.n - c0 < kChunk ? sc.n - c0 : kChunk;
             float* __restrict__ g = const_cast<float*>(sc.g) + c0;
             for (long long i = tid; i < n; i += 256)
                 if (g[i] != 0.f) g[i] = 0.f;
         }
         __syncthreads();
-        if (tid == 0) arrive(J);
+        if (tid == 0) arrive(J, gates);
         return;
     }
+    if (tid == 0) {
+        const double t = (double)J.step[seg] + 1.0;    // step[s] counts the segment's completed updates; this is number t
+        const double bc1 = 1.0 - pow(J.beta1, t), bc2 = 1.0 - pow(J.beta2, t);
+        s_hyp[0] = (float)((double)J.lrs[J.seg[seg].group] / (double)(float)bc1);   // step size
+        s_hyp[1] = (float)sqrt(bc2);
+    }
+    const int s_seg = seg;
     const TfAdamSeg& sg = J.seg[s_seg];
-    const float step_size = s_hyp[0], bc2_sqrt = s_hyp[1];
+    float step_size = 0.f, bc2_sqrt = 1.f;      // read from LDS behind the first batch's loads (thread 0 is still computing them)
     const long long c0 = (long long)((int)blockIdx.x - (s_seg ? J.chunk_end[s_seg - 1] : 0)) * kChunk;
     const long long n = sg.n - c0 < kChunk ? sg.n - c0 : kChunk;
     float* __restrict__ p = sg.p + c0;
@@ -113,6 +121,11 @@ __global__ __launch_bounds__(256) void adam_kernel(const TfAdamJob J) {
             mv[r] = in && old ? tf::ld4(m + 4 * i) : zero4;
             vv[r] = in && old ? tf::ld4(v + 4 * i) : zero4;
             pv[r] = in && old ? tf::ld4(p + 4 * i) : zero4;
+        }
+        if (b0 == 0) {
+            __syncthreads();
+            step_size = s_hyp[0];
+            bc2_sqrt = s_hyp[1];
         }
         // Entries whose gradient and both moments are zero stay exactly as they are (m = v = 0, update 0 / (0 + eps)):
         // a wave that holds only such entries neither reads the parameters nor writes anything back, which is exact.
@@ -158,7 +171,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const TfAdamJob J) {
     __syncthreads();
     // (thread 0 consumed step[] before the first barrier of this workgroup: no fence needed, and a device-scope fence
     //  here would write back the L2 once per workgroup)
-    if (tid == 0) arrive(J);
+    if (tid == 0) arrive(J, gates);
 }
 
 }  // namespace

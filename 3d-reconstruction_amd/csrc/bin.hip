@@ -102,7 +102,16 @@ __device__ __forceinline__ int key_groups(const KeyMap& K, int key) {
     if (key >= K.line_base[0]) return K.ncg[key >= K.line_base[2] ? 2 : (key >= K.line_base[1] ? 1 : 0)];
     return K.ncg[key >= K.plane_base[2] ? 2 : (key >= K.plane_base[1] ? 1 : 0)];
 }
-constexpr int kItemKeyBits = 20;       // work item = key | group << 20  (TF_BIN_MAX_KEYS = 2^18 keys, <= 2^11 groups)
+constexpr int kItemKeyBits = 20;       // work item word 0 = key | group << 20  (TF_BIN_MAX_KEYS = 2^18 keys, <= 2^11 groups)
+// The work-item table behind chunk_off[nkeys + 1]: one int4 per item {key | group << 20, first position in binned[], end
+// position, 0}, written by the scan kernel.  (Round 2 stored the key word only: a scatter workgroup then chained item ->
+// offsets[key], chunk_off[key] -> binned[] -> coordinates, four dependent memory round trips in front of every work item —
+// 28 % of the kernel by its phase timers.  With the range in the item and the NEXT item fetched a whole item ahead the
+// chain starts at binned[].)
+typedef int item4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ item4_t* item_table(const TfBinJob& J, int nkeys) {
+    return reinterpret_cast<item4_t*>((reinterpret_cast<uintptr_t>(J.chunk_off + nkeys + 1) + 15) & ~(uintptr_t)15);
+}
 
 // threads per workgroup and workgroups per entry shard of the count / fill passes (measured at config 2:
 // 1 / 2 / 4 / 8 / 16 slices -> count 23 / 15 / 12.5 / 15 / 22 us, fill 50 / 32 / 24 / 31 / 50 us; 1024 threads: no change
@@ -186,7 +195,8 @@ __device__ __forceinline__ void scan_job(const SortArgs& A, int* sh) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // item table: work item -> key | group << kItemKeyBits; a key's items are laid out group by group, so the chunk index
     // is (item - chunk_off[key]) - group * chunks(key); lives behind chunk_off[]
-    int* items = J.chunk_off + nkeys + 1;
+    item4_t* items = item_table(J, nkeys);
+    int* so = sh + min(nkeys, kKeyRange);       // the range's entry prefixes (offsets), kept for the item ranges
     const int cm1 = J.chunk - 1;
     int carry = 0, carry2 = 0;
     for (int k0 = 0; k0 < nkeys; k0 += kKeyRange) {
@@ -256,6 +266,7 @@ __device__ __forceinline__ void scan_job(const SortArgs& A, int* sh) {
             const int o = sh[i];
             J.offsets[k0 + i] = o;
             J.cursor[k0 + i] = o;
+            so[i] = o;
         }
         __syncthreads();
         // chunk prefixes: the counts are recovered from neighbouring offsets (sh holds them; the end of the thread's
@@ -279,9 +290,12 @@ __device__ __forceinline__ void scan_job(const SortArgs& A, int* sh) {
             // tf_shade_forward, where a dependent load costs microseconds
             const int n_it = (i + 1 < kn ? sh[i + 1] : carry2 + tot2) - co;
             const int ng = n_it ? groups_of(k0 + i) : 0, nc = ng > 1 ? n_it / ng : n_it;
+            const int kbeg = so[i], kend = i + 1 < kn ? so[i + 1] : carry + tot;
             for (int g = 0; g < ng; ++g)
                 for (int c = 0; c < nc; ++c) {
-                    if (co + g * nc + c < J.items_cap) items[co + g * nc + c] = (k0 + i) | (g << kItemKeyBits);
+                    const int b = kbeg + c * J.chunk;
+                    if (co + g * nc + c < J.items_cap)
+                        items[co + g * nc + c] = (item4_t){(k0 + i) | (g << kItemKeyBits), b, min(kend, b + J.chunk), 0};
                     else flag(J, TF_BIN_ERR_ITEMS);
                 }
         }
@@ -390,6 +404,8 @@ __global__ __launch_bounds__(256, 5) void bin_scatter_kernel(const TfBinJob J, c
     const int entry_cap = TF_N_SHARDS * J.seg_cap;
     const size_t rep = (size_t)(blockIdx.x % J.grads.n_rep) * J.grads.rep_stride;
     TF_T0();
+    const item4_t* items = item_table(J, K.nkeys);
+    item4_t it_next = (int)blockIdx.x < total ? items[blockIdx.x] : (item4_t){0, 0, 0, 0};
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
         TF_MARK(7);
         // per-thread coordinates from an opaque copy of the thread id: nothing derived from it is hoisted out of the
@@ -401,21 +417,17 @@ __global__ __launch_bounds__(256, 5) void bin_scatter_kernel(const TfBinJob J, c
         float* pre = smem + wave * wstride;            // [ER][C]
         float* meta = pre + ER * cmax;                 // [ER][8]: cell (int), w00, w01, w10, w11 | cell, w0, w1
         float* blk0 = smem + 4 * wstride;              // 4 private accumulation blocks (one per wave)
-        const int item = J.chunk_off[K.nkeys + 1 + w];
-        const int key = item & ((1 << kItemKeyBits) - 1);
-        int cg = (int)((unsigned)item >> kItemKeyBits);
-        if ((unsigned)key >= (unsigned)K.nkeys || cg >= key_groups(K, key)) {   // not an item: a slot the scan never wrote
-            if (threadIdx.x == 0) flag(J, TF_BIN_ERR_ITEMS);
+        // this item's descriptor was fetched while the previous item was processed; the next one's is requested now
+        // (wave-uniform: scalar loads)
+        const item4_t it = it_next;
+        if (w + (int)gridDim.x < total) it_next = items[w + gridDim.x];
+        const int key = it[0] & ((1 << kItemKeyBits) - 1);
+        int cg = (int)((unsigned)it[0] >> kItemKeyBits);
+        int beg = it[1], end = it[2];
+        if ((unsigned)key >= (unsigned)K.nkeys || cg >= key_groups(K, key) || beg > end || end - beg > J.chunk) {
+            if (threadIdx.x == 0) flag(J, TF_BIN_ERR_ITEMS);       // not an item: a slot the scan never wrote
             continue;
         }
-        const int kbeg = J.offsets[key], kend = J.offsets[key + 1];
-        const int nchunks = (kend - kbeg + J.chunk - 1) / J.chunk;
-        const int chunk = (w - J.chunk_off[key]) - cg * nchunks;          // the key's items: group by group
-        if (chunk < 0 || chunk >= nchunks) {
-            if (threadIdx.x == 0) flag(J, TF_BIN_ERR_ITEMS);
-            continue;
-        }
-        int beg = kbeg + chunk * J.chunk, end = min(kend, beg + J.chunk);
         if (beg < 0 || end > J.binned_cap) {      // (ranges outside binned[] are dropped and reported)
             if (threadIdx.x == 0) flag(J, TF_BIN_ERR_BINNED);
             beg = max(beg, 0);
@@ -675,9 +687,10 @@ static int launch_sort(const TfBinJob* const jobs[2], int n, hipStream_t st) {
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(bin_count_kernel), (size_t)(lds));
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(bin_count_kernel, dim3(n * kSortWgs), dim3(kSortThreads), lds, st, A);
-    e = ensure_dynamic_lds(reinterpret_cast<const void*>(bin_scan_kernel), (size_t)(lds));
+    const size_t lds_scan = 2 * lds_need > lds ? 2 * lds_need : lds;      // histogram / prefixes + the entry offsets of the range
+    e = ensure_dynamic_lds(reinterpret_cast<const void*>(bin_scan_kernel), (size_t)(lds_scan));
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(n), dim3(kScanThreads), lds, st, A);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(n), dim3(kScanThreads), lds_scan, st, A);
     e = ensure_dynamic_lds(reinterpret_cast<const void*>(bin_fill_kernel), (size_t)(lds));
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(bin_fill_kernel, dim3(n * kSortWgs), dim3(kSortThreads), lds, st, A);

@@ -238,7 +238,9 @@ class _Workspace:
             if binned is not None:   # binned gradient scatter (csrc/bin.hip): entry lists + sort workspace
                 nkeys, kpe = max(binned[0], binned[1]), binned[2]
                 kpe_d, kpe_a = binned[6], binned[7]          # (key, group) pairs per entry of the density / appearance job
-                n_ints = 4 * (nkeys + 8) + max(kpe_a * cap, kpe_d * ecap) // 128 + 64      # work items: <= pairs / chunk + keys, chunk >= 256
+                # offsets, cursor, chunk_off (3 x nkeys) + the work-item table: one int4 per item, <= pairs / chunk (chunk >= 256)
+                # + one partial item per (key, group)
+                n_ints = 4 * (nkeys + 8) + 4 * (max(kpe_a * cap, kpe_d * ecap) // 256 + nkeys + 8) + 64
                 # one sort workspace per job (density, appearance): both sorts run early, next to the shading kernels
                 spec += [("ent_xyz", ecap * 3, torch.float32), ("ent_df", ecap, torch.float32), ("ent_offset", R, torch.int32),
                          ("binned", kpe_d * ecap, torch.int32), ("bin_ints", n_ints, torch.int32),

@@ -462,8 +462,9 @@ def main():
         # first, WITHOUT the events — they cost ~40 % on this host-bound loop
         if use_graph:
             opt, model.static_jitter = make_opt(False), None
-            # (the captured step sorts beside the shading kernel on a second stream; the kernels are timed one at a time)
-            model.early_sort = False
+            # (the captured step sorts beside the shading kernel on a second stream; for the per-kernel table the same
+            #  launches are issued on ONE stream, so that every kernel is timed alone)
+            model._sort_inline = True
         inst_step = train_step if args.mode == "train" else eval_step
         n_e = min(20, args.steps)
         for i in range(3):

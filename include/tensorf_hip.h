@@ -374,7 +374,8 @@ typedef struct TfBinJob {
     int grad_ld;              /* 0: one scalar per entry, broadcast over components; else row stride */
     int tile, bucket, chunk;  /* T, LB, max entries per workgroup */
     /* workspace (ints): hist[nkeys] (read, then left as is), offsets[nkeys+1], cursor[nkeys], chunk_off[nkeys+1] followed by the
-     * work-item table (groups*nkeys + kpe*entries/chunk ints, groups = most 16-component groups of a plane / line);
+     * work-item table (16-byte aligned; one int4 per item: {key | group << 20, first position in binned[], end position, 0},
+     * at most groups*nkeys + kpe*entries/chunk items, groups = most 16-component groups of a plane / line);
      * binned[kpe*entries], kpe = tf_bin_keys_per_entry */
     int* hist; int* offsets; int* cursor; int* chunk_off; int* binned;
     int nkeys;
@@ -383,7 +384,7 @@ typedef struct TfBinJob {
                                * grad: can run as soon as the entry coordinates exist, on another stream); 2: scatter
                                * only, the workspace holds the result of an earlier stage-1 call of the same job */
     int binned_cap;           /* ints in binned[]; */
-    int items_cap;            /* ints in the work-item table behind chunk_off[nkeys + 1] */
+    int items_cap;            /* int4 ITEMS the work-item table behind chunk_off[nkeys + 1] holds */
     int share_groups;         /* 1: one sort key per (sample, plane | line) — the 16-component groups share it and the work-item
                                * table carries the group (cheapest sort: eager steps, large configurations); 0: one key per
                                * group (what runs best beside tf_shade_forward on the second stream: the captured step) */
