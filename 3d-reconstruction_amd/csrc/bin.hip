@@ -396,6 +396,7 @@ __host__ __device__ inline int lane_group(int c) { return c <= 16 ? 16 : (c <= 3
 __global__ __launch_bounds__(256, 5) void bin_scatter_kernel(const TfBinJob J, const KeyMap K, int ER, int cmax) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wstride = ER * (cmax + 8);
+    const int blk_floats = max((K.T + 1) * (K.T + 1), K.LB + 1) * cmax;      // one wave's accumulation block (launch sizing)
     int total = J.chunk_off[K.nkeys];
     if (total > J.items_cap) {          // never walk past the item table (a histogram that does not match the entries)
         total = J.items_cap;
@@ -405,8 +406,18 @@ __global__ __launch_bounds__(256, 5) void bin_scatter_kernel(const TfBinJob J, c
     const size_t rep = (size_t)(blockIdx.x % J.grads.n_rep) * J.grads.rep_stride;
     TF_T0();
     const item4_t* items = item_table(J, K.nkeys);
-    item4_t it_next = (int)blockIdx.x < total ? items[blockIdx.x] : (item4_t){0, 0, 0, 0};
-    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+    // The NEXT work item's descriptor travels global -> LDS by DMA while the current item is processed (no registers: a
+    // prefetch held in VGPRs across the item cost 50 spilled dwords at this kernel's 96-register budget): two 16-byte
+    // slots behind the accumulation blocks, lanes 0..3 of wave 0 carry one int each.
+    int* dslot = reinterpret_cast<int*>(smem + 4 * wstride + 4 * blk_floats);
+    auto request_item = [&](int wn, int slot) {
+        if (threadIdx.x < 4 && wn < total)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const int*>(items + wn) + threadIdx.x),
+                                             (__attribute__((address_space(3))) void*)(dslot + 4 * slot), 4, 0, 0);
+    };
+    request_item((int)blockIdx.x, 0);
+    int par = 0;
+    for (int w = blockIdx.x; w < total; w += gridDim.x, par ^= 1) {
         TF_MARK(7);
         // per-thread coordinates from an opaque copy of the thread id: nothing derived from it is hoisted out of the
         // work-item loop, which keeps the kernel at 5 waves per SIMD (96 VGPRs; 5 dwords of it live in scratch, four of
@@ -417,10 +428,15 @@ __global__ __launch_bounds__(256, 5) void bin_scatter_kernel(const TfBinJob J, c
         float* pre = smem + wave * wstride;            // [ER][C]
         float* meta = pre + ER * cmax;                 // [ER][8]: cell (int), w00, w01, w10, w11 | cell, w0, w1
         float* blk0 = smem + 4 * wstride;              // 4 private accumulation blocks (one per wave)
-        // this item's descriptor was fetched while the previous item was processed; the next one's is requested now
-        // (wave-uniform: scalar loads)
-        const item4_t it = it_next;
-        if (w + (int)gridDim.x < total) it_next = items[w + gridDim.x];
+        // this item's descriptor was requested one item ago (wave 0 waits for its own DMA, the barrier tells the others);
+        // the next one's is requested now, into the other slot (rewritten two items later, behind two barriers)
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const item4_t itv = *reinterpret_cast<const item4_t*>(dslot + 4 * par);
+        item4_t it;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) it[q] = __builtin_amdgcn_readfirstlane(itv[q]);
+        request_item(w + (int)gridDim.x, par ^ 1);
         const int key = it[0] & ((1 << kItemKeyBits) - 1);
         int cg = (int)((unsigned)it[0] >> kItemKeyBits);
         int beg = it[1], end = it[2];
@@ -713,7 +729,7 @@ int tf_binned_scatter(const TfBinJob* job, tf_stream_t stream) {
     const size_t blk_bytes = (size_t)(job->tile + 1) * (job->tile + 1) * cmax * 4;
     const size_t lblk_bytes = (size_t)(job->bucket + 1) * cmax * 4;
     const int ER = entries_per_round(cmax);
-    const size_t sc_bytes = 4 * (blk_bytes > lblk_bytes ? blk_bytes : lblk_bytes) + (size_t)4 * ER * (cmax + 8) * 4;
+    const size_t sc_bytes = 4 * (blk_bytes > lblk_bytes ? blk_bytes : lblk_bytes) + (size_t)4 * ER * (cmax + 8) * 4 + 32;   // + 2 item slots
     if (sc_bytes > 150 * 1024) return (int)hipErrorInvalidValue;
     int per_cu = (int)((160 * 1024) / (sc_bytes + 512));
     // (never more workgroups than are resident at once — 5 per CU by registers: the items are dealt by a fixed stride, and
