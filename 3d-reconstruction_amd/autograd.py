@@ -194,7 +194,9 @@ class _RenderFn(torch.autograd.Function):
                 model._need_prev[(ws.R, ws.N)] = need
                 f = [min(4.0, max(1.3, (need[i] / prev[i]) ** 2 if prev[i] > 0 else 1.3)) for i in (0, 1)]
                 if need[0] * f[0] > ws.seg_cap or need[1] * f[1] > ws.ent_seg_cap:
-                    model._grow_caps(ws.R, ws.N, need[0] * f[0] / 1.3, need[1] * f[1] / 1.3)
+                    # (a quarter more than the trigger level: batch-to-batch fluctuations of a few per cent must not grow —
+                    #  and re-validate — the workspace every other step)
+                    model._grow_caps(ws.R, ws.N, need[0] * f[0] * 1.25, need[1] * f[1] * 1.25, factor=1.0)
             if not model.reference_none_grads:
                 n_density = n_shaded = 1
         out = tuple((grads[n] if (n_density if n.startswith('density_') else n_shaded) else None) if p.requires_grad else None

@@ -58,8 +58,11 @@ __global__ __launch_bounds__(256) void adam_kernel(const TfAdamJob J) {
     // segment and gate of this workgroup: wave-uniform arithmetic on kernel arguments and a handful of scalar loads, done
     // by every thread (no LDS hand-over in front of the first memory request)
     const Gates gates = load_gates(J);
+    // (counted over the whole table: 31 independent compares on two wide scalar loads — the `while` walk it replaces was a
+    //  chain of up to n_seg dependent scalar loads in front of every workgroup's first memory request)
     int seg = 0;
-    while (seg + 1 < J.n_seg && (int)blockIdx.x >= J.chunk_end[seg]) ++seg;
+#pragma unroll
+    for (int s = 0; s < TF_ADAM_MAX_SEG - 1; ++s) seg += (s + 1 < J.n_seg && (int)blockIdx.x >= J.chunk_end[s]) ? 1 : 0;
     const bool open = seg_open(J, gates, seg);
     if (!open) {             // a parameter without a gradient this step: untouched, like torch.optim.Adam's `grad is None`
         // ... but a caller that accumulates the next step into the same buffer (clear_grads) must get it back clean: a

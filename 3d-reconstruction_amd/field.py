@@ -969,8 +969,8 @@ class TensorBase(nn.Module):
             need_app, need_ent = int(ctr[:, 0].max()), int(ctr[:, 1].max())      # per-shard demand (slot 1 >= the entries)
             if int(ctr[0, H.OVERFLOW_SLOT]) == 0 and need_ent <= ws.ent_seg_cap:
                 ws.validated, ws.alpha_ref = True, self.alphaMask
-                if need_app > 0.7 * ws.seg_cap or need_ent > 0.7 * ws.ent_seg_cap:
-                    self._grow_caps(R, N, need_app, need_ent)        # (this workspace still serves; the next ones are larger)
+                if need_app * 1.3 > ws.seg_cap or need_ent * 1.3 > ws.ent_seg_cap:
+                    self._grow_caps(R, N, need_app, need_ent, factor=1.6)     # (this workspace still serves; the next ones are larger)
                 break
             self._grow_caps(R, N, need_app, need_ent)
             ws.busy, ws.owner = False, None
