@@ -221,6 +221,33 @@ def lib():
     return _lib
 
 
+class PinnedRing:
+    """Small host -> device uploads that recur every training step (learning rates, regulariser weights, FreeNeRF mask
+    values): a ring of pinned staging buffers allocated ONCE.  `torch.tensor(v).pin_memory()` per upload goes through the
+    pinned allocator every time — measured as the larger part of a millisecond of host time per iteration of the captured
+    training loop once the rates decay every step (train.py:391-392).  A slot is rewritten only after the copy that read
+    it has run (its event): the host may be many replays ahead of the GPU."""
+
+    def __init__(self, n, depth=64):
+        import torch
+        self._torch = torch
+        self._slots = [[torch.empty(n, dtype=torch.float32).pin_memory(), None] for _ in range(depth)]
+        self._i = 0
+
+    def upload(self, dst, values):
+        torch = self._torch
+        buf, ev = self._slots[self._i % len(self._slots)]
+        if ev is not None:
+            ev.synchronize()
+        src = values if torch.is_tensor(values) else torch.tensor(values, dtype=torch.float32)
+        buf[:src.numel()].copy_(src.reshape(-1))
+        dst.reshape(-1)[:src.numel()].copy_(buf[:src.numel()], non_blocking=True)
+        if ev is None:
+            ev = self._slots[self._i % len(self._slots)][1] = torch.cuda.Event()
+        ev.record()
+        self._i += 1
+
+
 def check(err, what):
     if err != 0:
         raise HipError(f"{what} failed with hipError_t {err}")

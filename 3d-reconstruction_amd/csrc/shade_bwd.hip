@@ -49,40 +49,10 @@ __device__ __forceinline__ void ldv(const float* p, float (&v)[E]) {
     }
 }
 
-// NT (2, 4, 5 or 6) column tiles starting at p (16-float aligned columns) for lane index r:
-//   tiles 0..3 through one 16-B read (tile t = column 4 r + t), the rest through an 8-B / 4-B read at +64
-template <int NT>
-__device__ __forceinline__ void ld_tiles(const float* p, int r, float (&v)[NT]) {
-    if constexpr (NT == 2) {
-        float t[2];
-        ldv<2>(p + 2 * r, t);
-        v[0] = t[0]; v[1] = t[1];
-    } else {
-        float t[4];
-        ldv<4>(p + 4 * r, t);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = t[e];
-        if constexpr (NT == 5) {
-            v[4] = p[64 + r];
-        } else if constexpr (NT == 6) {
-            float u[2];
-            ldv<2>(p + 64 + 2 * r, u);
-            v[4] = u[0]; v[5] = u[1];
-        }
-    }
-}
-// column (relative to p) that tile t of ld_tiles<NT> holds for lane index j
-__host__ __device__ inline int tile_col(int NT, int t, int j) {
-    if (NT == 2) return 2 * j + t;
-    if (t < 4) return 4 * j + t;
-    return NT == 5 ? 64 + j : 64 + 2 * j + (t - 4);
-}
-
 // acc[ea][eb] += sum_s A[s][a0 + EA i + ea] * B[s][b0 + EB j + eb]  (s = 0 .. 4 ksteps - 1), both operands in LDS,
-// sample-major rows: the "TN" weight-gradient GEMM.  Software-pipelined one k-step ahead.
-// HILO_A: the A operand is stored as [hi | lo] words (tf_shade.h): its values are rebuilt (hi + lo, 16 mantissa bits) as
-// they are read — the weight-gradient sums stay on the fp32 pipe.
-template <int EA, int EB, bool HILO_A = false>
+// sample-major rows: the fp32 "TN" weight-gradient GEMM (dB, P7; the large ones are tn_block_hilo below).  Software-
+// pipelined one k-step ahead.
+template <int EA, int EB>
 __device__ __forceinline__ void tn_block(const float* A, int lda, int a0, const float* B, int ldb, int b0, int ksteps,
                                           f32x4 (&acc)[EA][EB], int lane) {
     const int r = lane & 15, kq = lane >> 4;
@@ -97,10 +67,6 @@ __device__ __forceinline__ void tn_block(const float* A, int lda, int a0, const 
         const int tn = t + 1 < ksteps ? t + 1 : t;
         ldv<EA>(ap + 4 * tn * lda, an);
         ldv<EB>(bp + 4 * tn * ldb, bn);
-        if constexpr (HILO_A) {
-#pragma unroll
-            for (int ea = 0; ea < EA; ++ea) a[ea] = unpack_hilo(a[ea]);
-        }
 #pragma unroll
         for (int ea = 0; ea < EA; ++ea)
 #pragma unroll
@@ -296,7 +262,6 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
     const int tid0 = threadIdx.x;
     const int kp1 = kpad16(S.in_c), kt1 = kp1 / 16, kpB = kpad16(S.n_app_total), ktB = kpB / 16;
     const int xq4 = kp1 / 4, nat = S.n_app_total, vq4 = nat >> 2;
-    const float inv_xq4 = 1.f / (float)xq4, inv_vq4 = 1.f / (float)(vq4 > 0 ? vq4 : 1);
     const bool v_vec = (nat & 3) == 0;            // V / dV rows are 16-B aligned
     const float* __restrict__ xs = G.x_saved;
     float* __restrict__ dv = G.dv_out;            // V rows on entry, dL/dV rows on exit

@@ -154,10 +154,6 @@ __device__ __forceinline__ float pack_hilo(float x) {
     const unsigned r = __float_as_uint(x - __uint_as_float(hb));                 // exact
     return __uint_as_float(hb | ((r + 0x7FFFu + ((r >> 16) & 1u)) >> 16));       // lo: round to nearest even
 }
-__device__ __forceinline__ float unpack_hilo(float w) {
-    const unsigned b = __float_as_uint(w);
-    return __uint_as_float(b & 0xFFFF0000u) + __uint_as_float(b << 16);
-}
 // fp32 weight fragment (four consecutive k of one row) -> the two A operands above
 __device__ __forceinline__ void split_weight_frag(const f32x4& w, bf16x8& a1, bf16x8& a2) {
     u32x4 p1, p2;

@@ -79,6 +79,7 @@ class GraphedTrainStep:
         # FreeNeRF masks (train.py:303-318: a new mask dict every iteration with `free_reg`): the step keeps every mask
         # vector in ONE static device buffer the captured kernels read; set_mask() refreshes its values before a replay
         self.mask, self._mask_buf, self._mask_sig = None, None, None
+        self._mask_ring, self._mask_ring_n, self._regw_ring = None, 0, None
         # white_bg=False (datasets without a white background, e.g. llff.py:141): the reference adds the white
         # background to a training batch with probability 1/2 (tensorBase.py:380) — a host decision per step, so the
         # step is captured once per outcome and the draw (same generator, same position in the stream) picks the graph
@@ -206,7 +207,9 @@ class GraphedTrainStep:
         if rows:
             host = torch.cat([torch.broadcast_to(torch.as_tensor(v, dtype=torch.float32).detach().cpu().reshape(-1), (n,))
                               for _, _, _, n, v in rows])
-            self._mask_buf.copy_(host.pin_memory(), non_blocking=True)
+            if self._mask_ring is None or self._mask_ring_n < host.numel():
+                self._mask_ring, self._mask_ring_n = H.PinnedRing(host.numel()), host.numel()
+            self._mask_ring.upload(self._mask_buf, host)
 
     def set_regularizer_weights(self, ortho=0.0, l1=0.0, tv_density=0.0, tv_app=0.0):
         """Weights of the four regulariser terms for the next step(s) (needs regularizers=True)."""
@@ -214,7 +217,9 @@ class GraphedTrainStep:
         if hasattr(self.opt, "set_regularizer_activity"):     # terms that are on give their tensors a gradient in every step
             self.opt.set_regularizer_activity(*[v > 0 for v in vals])
         if vals != self._regw_host:
-            self._regw.copy_(torch.tensor(vals).pin_memory(), non_blocking=True)
+            if self._regw_ring is None:
+                self._regw_ring = H.PinnedRing(4)
+            self._regw_ring.upload(self._regw, vals)
             self._regw_host = vals
 
     # ---- data-parallel pieces (no autograd: the launches are issued directly, so the backward can be cut in two) -----

@@ -27,15 +27,20 @@ from .utils import N_to_reso, cal_n_samples, get_free_mask
 class SimpleSampler:
     """train.py:44-56."""
 
-    def __init__(self, total, batch, seed=None):
+    def __init__(self, total, batch, seed=None, device=None):
         self.total, self.batch, self.curr, self.ids = total, batch, total, None
         self.rng = np.random.default_rng(seed) if seed is not None else None
+        # device: the permutation is uploaded ONCE per epoch and sliced there — a 4096-index H2D copy per step (pageable
+        # memory: a stream synchronisation) would tie the host to the GPU in every iteration of the captured loop
+        self.device = device
 
     def nextids(self):
         self.curr += self.batch
         if self.curr + self.batch > self.total:
             perm = self.rng.permutation(self.total) if self.rng is not None else np.random.permutation(self.total)
             self.ids = torch.LongTensor(perm)
+            if self.device is not None:
+                self.ids = self.ids.to(self.device)
             self.curr = 0
         return self.ids[self.curr:self.curr + self.batch]
 
@@ -84,7 +89,6 @@ def train(tensorf, allrays, allrgbs, cfg=None, device="cuda", rank=0, world=1, l
     tv_d, tv_a = c["TV_weight_density"], c["TV_weight_app"]
     if not c["ndc_ray"]:
         allrays, allrgbs = tensorf.filtering_rays(allrays, allrgbs, bbox_only=True)      # train.py:291
-    sampler = SimpleSampler(allrays.shape[0], batch * world, seed)
     hist = dict(loss=[], psnr=[], events=[], n_samples=[])
     # park the objects that exist now in the collector's permanent generation: at ~1 ms per step a full cyclic
     # collection over the set-up's long-lived objects (a few ms) would otherwise recur every handful of steps
@@ -100,6 +104,9 @@ def train(tensorf, allrays, allrgbs, cfg=None, device="cuda", rank=0, world=1, l
         # eager data parallel: the density gradients leave during the backward (only where nothing else touches .grad
         # before the exchange: the autograd regularisers of the other branch accumulate into it asynchronously)
         parallel.enable_overlapped_exchange(tensorf)
+    # (rays on the GPU: the batch indices live there too, one upload per epoch)
+    sampler_dev = allrays.device if allrays.is_cuda else None
+    sampler = SimpleSampler(allrays.shape[0], batch * world, seed, device=sampler_dev)
     gc.collect()
     gc.freeze()
     mask = None
@@ -174,7 +181,7 @@ def train(tensorf, allrays, allrgbs, cfg=None, device="cuda", rank=0, world=1, l
                 hist["events"].append((it, "shrink", tensorf.gridSize.tolist()))
             if not c["ndc_ray"] and it == mask_list[-1] and len(mask_list) > 1:
                 allrays, allrgbs = tensorf.filtering_rays(allrays, allrgbs)
-                sampler = SimpleSampler(allrays.shape[0], batch * world, seed + it)
+                sampler = SimpleSampler(allrays.shape[0], batch * world, seed + it, device=sampler_dev)
             # shrink replaced the parameters: the optimizer is rebuilt at the CURRENT learning rates (decayed it + 1 times)
             opt = make_opt(c["lr_init"] * lr_factor ** (it + 1), c["lr_basis"] * lr_factor ** (it + 1))
         if it in upsamp_list:                                                              # train.py:468-481

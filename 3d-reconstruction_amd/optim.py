@@ -44,6 +44,11 @@ class FusedAdam(torch.optim.Optimizer):
     def _params(self):
         return [(gi, p) for gi, g in enumerate(self.param_groups) for p in g['params'] if p.requires_grad]
 
+    def _uploads(self):
+        if getattr(self, "_ring", None) is None:
+            self._ring = H.PinnedRing(max(8, len(self.param_groups)))
+        return self._ring
+
     def set_regularizer_activity(self, ortho=False, l1=False, tv_density=False, tv_app=False):
         """Which regulariser terms are part of the loss (train.py:340-371: `if Ortho_reg_weight > 0 ...`).  They give the
         factor tensors a gradient whether or not the batch produced samples, so they open those tensors' gates
@@ -54,7 +59,7 @@ class FusedAdam(torch.optim.Optimizer):
             if self._reg_active is not None:
                 if torch.cuda.is_current_stream_capturing():
                     raise H.HipError("FusedAdam: regulariser activity changed inside a graph capture")
-                self._reg_active.copy_(torch.tensor(flags).pin_memory(), non_blocking=True)
+                self._uploads().upload(self._reg_active, flags)
 
     def _init_state(self, ps):
         dev = ps[0][1].device
@@ -108,10 +113,9 @@ class FusedAdam(torch.optim.Optimizer):
         if lrs != self._lr_host:
             if torch.cuda.is_current_stream_capturing():
                 raise H.HipError("FusedAdam: learning rates changed inside a graph capture")
-            # a FRESH pinned tensor per upload (the caching host allocator keeps it alive until the copy has run): with
-            # graph replays the host runs many steps ahead of the GPU, and rewriting one staging buffer would let the
-            # copy of step k read the rates of a later step
-            self._lr_dev.copy_(torch.tensor(lrs, dtype=torch.float32).pin_memory(), non_blocking=True)
+            # through a ring of pinned staging buffers (H.PinnedRing): with graph replays the host runs many steps ahead of
+            # the GPU, and rewriting ONE staging buffer would let the copy of step k read the rates of a later step
+            self._uploads().upload(self._lr_dev, lrs)
             self._lr_host = lrs
 
     def _build_jobs(self, ps):
