@@ -92,3 +92,42 @@ def test_first_iterations_of_a_fresh_field_follow_the_reference_adam_trajectory(
         assert float(opt.state[p[k]]["step"]) == float(z["adam_step/" + k]), k
         np.testing.assert_allclose(p[k].detach().numpy(), z["final/" + k], rtol=0, atol=2e-5 * np.abs(z["final/" + k]).max(),
                                    err_msg=k)
+
+
+def test_shrink_params_is_the_reference_crop():
+    """shrink(new_aabb) of the reference (tensoRF.py:291-327) on the fixture: every cropped tensor bit-equal, same box,
+    grid, stepSize and nSamples."""
+    z = _npz("lifecycle")
+    cfg = _cfg([32, 32, 32])
+    cfg.alpha_volume, cfg.alpha_aabb = torch.from_numpy(z["upd/alpha"]).float(), torch.tensor(CUBE)
+    out = R.shrink_params(cfg, _state(z, "state0/"), torch.from_numpy(z["upd/new_aabb"]))
+    assert cfg.gridSize == z["shrunk/gridSize"].tolist()
+    assert np.array_equal(cfg.aabb.numpy(), z["shrunk/aabb"])
+    assert float(cfg.stepSize) == float(z["shrunk/stepSize"]) and cfg.nSamples == int(z["shrunk/nSamples"])
+    for k, v in out.items():
+        assert np.array_equal(v.detach().numpy(), z["shrunk/" + k]), k
+
+
+def test_filter_rays_keeps_the_reference_set():
+    z = _npz("lifecycle")
+    cfg = _cfg([32, 32, 32])
+    cfg.alpha_volume, cfg.alpha_aabb = torch.from_numpy(z["alpha0"]).float(), torch.tensor(CUBE)
+    rays = torch.from_numpy(z["frays"])
+    assert torch.nonzero(R.filter_rays(cfg, rays, bbox_only=True)).view(-1).tolist() == z["filter_bbox_kept"].tolist()
+    assert torch.nonzero(R.filter_rays(cfg, rays, n_samples=64)).view(-1).tolist() == z["filter_alpha_kept"].tolist()
+
+
+def test_regulariser_terms_are_the_reference_values():
+    """TVLoss values + gradients (aux_refs.npz: loss.py:120-141 run by the reference) and the line / L1 terms of the
+    lifecycle fixture (tensoRF.py:175-195)."""
+    a = _npz("aux_refs")
+    for tag in ("a", "b", "c"):
+        x = torch.from_numpy(a[f"tv/{tag}/x"]).requires_grad_(True)
+        y = R.tv_loss(x)
+        y.backward()
+        assert abs(float(y) - float(a[f"tv/{tag}/loss"])) <= 1e-6 * max(1.0, abs(float(a[f"tv/{tag}/loss"])))
+        np.testing.assert_allclose(x.grad.numpy(), a[f"tv/{tag}/grad"], rtol=1e-6, atol=1e-9)
+    z = _npz("lifecycle")
+    p = _state(z, "state0/")
+    assert abs(float(R.vector_comp_diffs(p)) - float(z["reg/vector_comp_diffs"])) < 1e-6
+    assert abs(float(R.density_l1(p)) - float(z["reg/density_L1"])) < 1e-6

@@ -11,6 +11,7 @@ appearance tensors and MLP have no gradient and torch.optim.Adam does not count 
 few steps ahead and the first appearance / MLP updates were up to 26 % smaller.  Fixed in autograd.py (None gradients)
 and FusedAdam (per-parameter step counts behind device-side gates; tests/test_adam_trajectory.py).  The bar is back at
 400 iterations, checked at several cut points and for a second seed."""
+import numpy as np
 import pytest
 
 from oracle import psnr_parity
@@ -37,3 +38,21 @@ def test_psnr_parity_through_mask_update_and_upsampling(recon, iters, seed):
     the end and at cut points before, between and after the events."""
     cuts = tuple(iters * k // 8 for k in (2, 4, 6, 7))
     _check(psnr_parity.run(recon, grid=64, iters=iters, schedule=True, init_grid=48, seed=seed, cuts=cuts))
+
+
+def test_psnr_parity_through_the_whole_schedule(recon):
+    """the reference's INTENDED schedule end to end — bbox ray filtering, MSE + ortho / L1 / TV terms with
+    decaying TV weights, alpha-mask update + SHRINK (L1 weight switched, optimizer rebuilt at the decayed rates), two
+    up-samplings (N rule of train.py:472, learning rates reset): the product's `harness.train`, eager AND captured,
+    against the same loop restated on the oracle, whose schedule steps and regulariser terms are pinned to the reference's
+    own outputs (tests/test_oracle_schedule.py).  Same events, same grids / boxes / sample counts, PSNR within 0.1 dB
+    (measured: HIP eager 34.53-34.57, captured 34.54-34.57, oracle 34.54-34.55 dB over repeated runs)."""
+    r = psnr_parity.run_full(recon)
+    print(r)
+    assert len(r["hip"]) == 2
+    for h in r["hip"]:
+        assert [e[:2] for e in h["events"]] == [e[:2] for e in r["events_eager"]], (h, r["events_eager"])
+        assert h["grid"] == r["grid_eager"] and h["n_samples"] == r["n_samples_eager"], (h, r)
+        assert np.allclose(np.array(h["aabb"]), np.array(r["aabb_eager"]), rtol=0, atol=1e-6), (h["aabb"], r["aabb_eager"])
+        assert h["psnr_hip_db"] > 30.0 and r["psnr_eager_db"] > 30.0, (h, r)
+        assert abs(h["delta_db"]) <= 0.1, (h, r["psnr_eager_db"])

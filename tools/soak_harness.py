@@ -77,6 +77,12 @@ for graphed in (True, False):
             print(f"   captured step on the trained field, regularizers={regs}: {dt1 / 100 * 1e3:.3f} ms per step (host issue {host / 100 * 1e3:.3f} ms), "
                   f"overflow re-runs {getattr(gs, 'overflow_reruns', 0)}", flush=True)
             del gs, opt
+    if graphed:      # ... and the harness loop itself on the trained field, no schedule events: its own overhead per iteration
+        cfg2 = dict(cfg, n_iters=400, upsamp_list=[], update_AlphaMask_list=[], N_voxel_init=300 ** 3, lr_init=0.002, lr_basis=1e-4)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        harness.train(student, rays, gt, cfg2, device=dev, log_every=0, seed=2, graphed=True)
+        torch.cuda.synchronize()
+        print(f"   harness.train(graphed=True) on the trained field, 400 iterations without events: {(time.perf_counter() - t1) / 400 * 1e3:.3f} ms per iteration", flush=True)
     del student
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats()
