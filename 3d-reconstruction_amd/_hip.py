@@ -170,6 +170,7 @@ _SIGS = {
     "tf_generate_rays": [C.POINTER(TfCamera), _fp, C.c_longlong, C.c_int, _fp, _fp],
     "tf_march_forward": [C.POINTER(TfField), C.POINTER(TfMarchIO), _fp],
     "tf_shade_forward": [C.POINTER(TfShade), _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, C.c_int, C.POINTER(TfShadeSave), _fp],
+    "tf_shade_forward_variant": [C.c_int],
     "tf_composite_forward": [C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp, _fp, C.POINTER(TfLive), _fp],
     "tf_composite_forward_loss": [C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp, _fp, C.POINTER(TfLossFuse),
                                   C.POINTER(TfLive), _fp],

@@ -395,6 +395,336 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
     TF_FLUSH();
 }
 
+// ---- the pipelined forward (packed list, MLP heads with feature_c = 128): round 3 ------------------------------------
+// Why: the kernel above spends a chunk in ~13 DEPENDENT global round trips (three tap stages, the basis and layer
+// weights, biases, W3, b3), and on a CU whose memory pipe is busy with the other workgroup's gather (~220 KB per chunk at
+// 11-18 B/cycle) every one of them queues behind that traffic: 65 k cycles per chunk and CU for 22 k cycles of MFMA
+// issue.  Here ONE 768-thread workgroup owns the CU and its 12 waves (three per SIMD: 168 VGPRs) are two crews working on
+// consecutive chunks:
+//   waves 0..7  (MLP crew)    chunk c:      B1  X -> H1         B2  H1 -> H2            B3  (training: H1 / H2 rows out)
+//   waves 8..11 (front crew)  chunk c + 1:  F1  gather -> V     F2  basis, view -> X'   F3  encodings -> X'; output layer of c
+// in lock step (three LDS-only barriers per iteration; s_barrier counts waves, whichever instruction they arrive at).  The
+// MLP crew keeps its slice of W1 and W2 (one 16-feature tile per wave, 72-80 VGPRs) and the biases in registers for the
+// whole launch and never waits for global memory; the gather, the only bulk fetch, runs beside the hidden layers'
+// MFMAs instead of in front of them.  LDS: X double-buffered (H2 overlays the X of its own chunk), V, H1 — 155.9 KB at
+// config 2.  Shapes that do not fit (or other heads / hidden widths) use the kernel above.
+struct PipeLds {
+    int sv, sx, sh, xw;
+    int offX0, offX1, offV, offH1, offInfo, offPre, total;
+};
+__host__ __device__ inline PipeLds pipe_lds(const TfShade& S) {
+    PipeLds L;
+    L.sv = kpad16(S.n_app_total) + 4;
+    L.sx = kpad16(S.in_c) + 4;
+    L.sh = S.feature_c + 4;
+    L.xw = L.sx > L.sh ? L.sx : L.sh;
+    L.offX0 = 0;
+    L.offX1 = M * L.xw;
+    L.offV = 2 * M * L.xw;
+    L.offH1 = L.offV + M * L.sv;
+    L.offInfo = L.offH1 + M * L.sh;
+    L.offPre = L.offInfo + M * 6;
+    L.total = L.offPre + 68;
+    return L;
+}
+
+#ifdef TF_PHASE_TIMING
+#define TF_PIPE_FLUSH(first_thread, arr) do { if ((int)threadIdx.x == (first_thread)) for (int _i = 0; _i < 16; ++_i) atomicAdd(&arr[_i], _ph[_i]); } while (0)
+#else
+#define TF_PIPE_FLUSH(first_thread, arr)
+#endif
+
+template <int KT1>
+__global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S, const TileSrc src, float* __restrict__ rgb_out,
+                                                                  const TfShadeSave save) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NC = 512, NCF = 256, FT = 8;       // threads of the MLP / front crew; feature tiles (feature_c = 128)
+    const PipeLds L = pipe_lds(S);
+    int* pre = reinterpret_cast<int*>(lds + L.offPre);
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int g = 0; g < TF_N_SHARDS; ++g) {
+            pre[g] = run;
+            run += min(src.counters[g * TF_SHARD_STRIDE], src.seg_cap);
+        }
+        pre[TF_N_SHARDS] = run;
+    }
+    __syncthreads();
+    const int total = pre[TF_N_SHARDS];
+    const long long n_tiles = (total + 15) / 16;
+    const int v_begin = (int)(((long long)blockIdx.x * n_tiles) / (long long)gridDim.x) * 16;
+    const int v_end = min(total, (int)((((long long)blockIdx.x + 1) * n_tiles) / (long long)gridDim.x) * 16);
+    // (a chunk is cut short where it would span a third shard — fwd_locate — so the chunk sequence is walked, not
+    // computed: both crews walk it alike, the MLP crew one chunk behind)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int kp1 = kpad16(S.in_c), kt1 = kp1 / 16;
+    float* H1 = lds + L.offH1;
+    TF_T0();
+
+    if (wave < 8) {
+        // ================= MLP crew: chunk it - 1 =================
+        const int f_base = 16 * wave, lg0 = lane >> 4;
+        f32x4 fr1[KT1][1], fr2[FT][1];
+        load_a_frags<1, KT1>(S.w1, kp1, f_base, kt1, lane, fr1);
+        load_a_frags<1, FT>(S.w2, 16 * FT, f_base, FT, lane, fr2);
+        const f32x4 bias1 = *reinterpret_cast<const f32x4*>(S.b1 + f_base + 4 * lg0);
+        const f32x4 bias2 = *reinterpret_cast<const f32x4*>(S.b2 + f_base + 4 * lg0);
+        FChunk ck;
+        ck.s0 = ck.n0 = ck.s1 = ck.n1 = 0;
+        bool on = false;
+        int v = v_begin;
+        for (int par = 0;; par ^= 1) {
+            // thread coordinates from an opaque copy of the thread id: no per-thread address is computed (and kept in
+            // registers) outside the chunk loop — the crew has ~40 registers beside its weights
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            const int lane = tid & 63, lc = lane & 15, lg = lane >> 4;
+            FChunk ck_front;
+            const bool more = fwd_locate(src, pre, v, v_end, ck_front);      // the front crew's chunk of this iteration
+            v += ck_front.n();
+            const int n = on ? ck.n() : 0, nt = (n + 15) >> 4;
+            float* X = lds + (par ? L.offX0 : L.offX1);      // the buffer the front crew filled in the previous iteration
+            auto at = [&](int r) { return ck.at(r); };
+            // ---- B1: H1 = relu(W1 X + b1)
+            if (on) {
+                if (save.x) save_rows<NC>(save.x, X, L.sx, kp1, n, tid, at);
+                f32x4 acc[1][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (nt > 2) mma_frags<1, 4, KT1>(fr1, X, L.sx, 0, kt1, acc, lane);
+                else mma_frags<1, 2, KT1>(fr1, X, L.sx, 0, kt1, reinterpret_cast<f32x4 (&)[1][2]>(acc), lane);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j >= nt) continue;
+                    f32x4 h = acc[0][j] + bias1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[e] = fmaxf(h[e], 0.f);
+                    *reinterpret_cast<f32x4*>(H1 + (16 * j + lc) * L.sh + f_base + 4 * lg) = h;
+                }
+            }
+            TF_MARK(0);
+            lds_barrier();
+            TF_MARK(1);
+            // ---- B2: H2 = relu(W2 H1 + b2), written over this chunk's X
+            if (on) {
+                f32x4 acc[1][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (nt > 2) mma_frags<1, 4, FT>(fr2, H1, L.sh, 0, FT, acc, lane);
+                else mma_frags<1, 2, FT>(fr2, H1, L.sh, 0, FT, reinterpret_cast<f32x4 (&)[1][2]>(acc), lane);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j >= nt) continue;
+                    f32x4 h = acc[0][j] + bias2;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[e] = fmaxf(h[e], 0.f);
+                    *reinterpret_cast<f32x4*>(X + (16 * j + lc) * L.sh + f_base + 4 * lg) = h;
+                }
+            }
+            TF_MARK(2);
+            lds_barrier();
+            TF_MARK(3);
+            // ---- B3: training rows
+            if (on) {
+                if (save.h1) save_rows<NC>(save.h1, H1, L.sh, 16 * FT, n, tid, at);
+                if (save.h2) save_rows<NC>(save.h2, X, L.sh, 16 * FT, n, tid, at);
+            }
+            TF_MARK(4);
+            lds_barrier();
+            TF_MARK(5);
+            if (!more) break;
+            ck = ck_front;
+            on = true;
+        }
+        TF_PIPE_FLUSH(0, tf_phase_cycles);
+    } else {
+        // ================= front crew: chunk it (and the output layer of chunk it - 1) =================
+        const int fw = wave - 8;
+        float* V = lds + L.offV;
+        float* ixyz = lds + L.offInfo;
+        float* iview = lds + L.offInfo + 3 * M;
+        const float b3[3] = {S.b3[0], S.b3[1], S.b3[2]};
+        // per-sample info, requested one iteration ahead: every lane of a sample's 4 holds its coordinates, lane 0 of the 4
+        // its view direction (app_ray -> rays: the second load is issued a phase later, when the first has arrived)
+        float nx_x[3] = {0.f, 0.f, 0.f}, nx_v[3] = {0.f, 0.f, 0.f};
+        int nx_ray = -1;
+        auto fetch_xyz = [&](const FChunk& c, int smp, int sub) {
+            nx_ray = -1;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) nx_x[a] = 0.f;
+            if (smp < c.n()) {
+                const size_t s = c.at(smp);
+                nx_x[0] = src.app_xyz[s * 3]; nx_x[1] = src.app_xyz[s * 3 + 1]; nx_x[2] = src.app_xyz[s * 3 + 2];
+                if (sub == 0 && src.rays) nx_ray = src.app_ray[s];
+            }
+        };
+        auto fetch_view = [&]() {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) nx_v[a] = 0.f;
+            if (nx_ray >= 0) {
+                const float* rp = src.rays + (size_t)nx_ray * 6 + 3;
+                nx_v[0] = rp[0]; nx_v[1] = rp[1]; nx_v[2] = rp[2];
+            }
+        };
+        {
+            FChunk c0;
+            if (fwd_locate(src, pre, v_begin, v_end, c0)) {
+                fetch_xyz(c0, (tid - NC) >> 2, tid & 3);
+                fetch_view();
+            }
+        }
+        FChunk ckm;
+        ckm.s0 = ckm.n0 = ckm.s1 = ckm.n1 = 0;
+        bool on_m = false;
+        int v = v_begin;
+        for (int par = 0;; par ^= 1) {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            const int lane = tid & 63, lc = lane & 15, lg = lane >> 4;
+            const int ftid = tid - NC, smp = ftid >> 2, sub = ftid & 3;      // gather: 4 lanes per sample
+            FChunk ckf;
+            const bool on_f = fwd_locate(src, pre, v, v_end, ckf);
+            v += ckf.n();
+            const int nf = on_f ? ckf.n() : 0, ntf = (nf + 15) >> 4, n16f = 16 * ntf;
+            const int nm = on_m ? ckm.n() : 0, ntm = (nm + 15) >> 4;
+            float* Xf = lds + (par ? L.offX1 : L.offX0);
+            const float* Xm = lds + (par ? L.offX0 : L.offX1);      // holds H2 of the previous chunk by phase 3
+            // ---- F1: sample info -> LDS, appearance gather -> V
+            if (on_f) {
+                if (sub == 0) {
+                    if (src.ndc && smp < nf) {   // viewdirs / rays_norm  (tensorBase.py:341-343)
+                        float q = nx_v[0] * nx_v[0];
+                        q = q + nx_v[1] * nx_v[1];
+                        q = q + nx_v[2] * nx_v[2];
+                        const float nrm = sqrtf(q);
+                        nx_v[0] = nx_v[0] / nrm; nx_v[1] = nx_v[1] / nrm; nx_v[2] = nx_v[2] / nrm;
+                    }
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        ixyz[smp * 3 + a] = nx_x[a];
+                        iview[smp * 3 + a] = nx_v[a];
+                    }
+                }
+                if (smp < n16f) {
+                    const float u[3] = {nx_x[0], nx_x[1], nx_x[2]};
+                    float* vrow = V + smp * L.sv;
+                    if (!app_products_lanes4(S, u, sub, vrow)) app_products(S, u, sub, vrow, 4);
+                    for (int c = S.n_app_total + sub; c < kpad16(S.n_app_total); c += 4) vrow[c] = 0.f;
+                }
+            }
+            TF_MARK(0);
+            lds_barrier();
+            TF_MARK(1);
+            // ---- F2: basis -> feat columns of X', view columns, training rows of V
+            if (on_f) {
+                const int nb = (S.app_dim + 15) >> 4, ktb = kpad16(S.n_app_total) / 16;
+                for (int pr = fw; pr < 4 * nb; pr += 4) {
+                    const int bf = pr >> 2, bs = pr & 3;
+                    if (bs >= ntf) continue;
+                    f32x4 acc[1][1];
+                    acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (ktb <= 9) {      // all weight fragments of the product requested at once
+                        f32x4 frb[9][1];
+                        load_a_frags<1, 9>(S.basis, 16 * ktb, 16 * bf, ktb, lane, frb);
+                        mma_frags<1, 1, 9>(frb, V, L.sv, 16 * bs, ktb, acc, lane);
+                    } else {
+                        mma_block<1, 1>(S.basis, 16 * ktb, 16 * bf, V, L.sv, 16 * bs, ktb, acc, lane);
+                    }
+                    const int row = 16 * bs + lc;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int f = 16 * bf + 4 * lg + e;
+                        if (f < S.app_dim) Xf[row * L.sx + f] = acc[0][0][e];
+                    }
+                }
+                if (ftid < M) {
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) Xf[ftid * L.sx + S.app_dim + a] = iview[ftid * 3 + a];
+                }
+                if (save.v) {
+                    const int nat = S.n_app_total;
+                    auto atf = [&](int r) { return ckf.at(r); };
+                    if ((nat & 3) == 0) {
+                        save_rows<NCF>(save.v, V, L.sv, nat, nf, ftid, atf);
+                    } else {
+                        for (int r = fw; r < nf; r += 4)
+                            for (int c = lane; c < nat; c += 64) save.v[ckf.at(r) * nat + c] = V[r * L.sv + c];
+                    }
+                }
+            }
+            TF_MARK(2);
+            lds_barrier();
+            TF_MARK(3);
+            // ---- F3: requests for later (next chunk's coordinates, W3), encodings of X', output layer of chunk it - 1
+            {
+                FChunk c1;
+                nx_ray = -1;
+                if (on_f && fwd_locate(src, pre, v, v_end, c1)) fetch_xyz(c1, smp, sub);
+                else { nx_x[0] = nx_x[1] = nx_x[2] = 0.f; }
+            }
+            f32x4 fr3[FT];
+            if (fw < ntm) {
+                const int r3 = lc < 3 ? lc : 2;
+#pragma unroll
+                for (int k = 0; k < FT; ++k) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(S.w3 + r3 * (16 * FT) + 16 * k + 4 * lg);
+                    fr3[k] = lc < 3 ? w : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (on_f) {
+                int off = S.app_dim + 3;
+                for (int b = 0; b < S.n_pe; ++b) {
+                    const int src_k = S.pe[b].src, F = S.pe[b].freqs;
+                    const int D = src_k == TF_SRC_FEAT ? S.app_dim : 3;
+                    const float* mk = S.pe[b].mask;
+                    const float* xb = Xf;
+                    const int sx = L.sx;
+                    pe_block<NCF>(Xf, L.sx, off, D, F, mk, ftid, [&](int s_, int d) {
+                        return src_k == TF_SRC_FEAT ? xb[s_ * sx + d] : (src_k == TF_SRC_VIEW ? iview[s_ * 3 + d] : ixyz[s_ * 3 + d]);
+                    }, n16f);
+                    off += 2 * D * F;
+                }
+                for (int i2 = ftid; i2 < n16f * 16; i2 += NCF) {     // the K padding is < 16 columns
+                    const int s_ = i2 >> 4, c = S.in_c + (i2 & 15);
+                    if (c < kp1) Xf[s_ * L.sx + c] = 0.f;
+                }
+            }
+            fetch_view();       // (the ray index asked for above has arrived behind the encodings)
+            if (fw < ntm) {     // o[c][s] = sum_f W3[c][f] H2[s][f]; W3 as rows 0..2 of a 16-row operand tile
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                const float* xp = Xm + (16 * fw + lc) * L.sh + 4 * lg;
+#pragma unroll
+                for (int k = 0; k < FT; ++k) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(xp + 16 * k);
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fr3[k][e], b[e], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fr3[k][e + 1], b[e + 1], acc1, 0, 0, 0);
+                    }
+                }
+                const f32x4 acc = acc0 + acc1;
+                const int row = 16 * fw + lc;      // D[c = 4 lg + reg][s = lc]: lanes 0..15 hold the three channels
+                if (lg == 0 && row < nm) {
+                    float* o = rgb_out + ckm.at(row) * 3;
+                    o[0] = 1.f / (1.f + expf(-(acc[0] + b3[0])));
+                    o[1] = 1.f / (1.f + expf(-(acc[1] + b3[1])));
+                    o[2] = 1.f / (1.f + expf(-(acc[2] + b3[2])));
+                }
+            }
+            TF_MARK(4);
+            lds_barrier();
+            TF_MARK(5);
+            if (!on_f) break;
+            ckm = ckf;
+            on_m = true;
+        }
+        TF_PIPE_FLUSH(512, tf_phase_cycles_w4);
+    }
+}
+
 typedef void (*shade_fn_t)(const TfShade, const TileSrc, float*, float*, const TfShadeSave);
 
 template <int FT>
@@ -432,9 +762,34 @@ int launch_shade(const TfShade* S, const TileSrc& src, float* rgb_out, float* fe
     return TF_CHECK_LAUNCH();
 }
 
+// 0 = pipelined kernel wherever its shape conditions hold, 1 = the two-workgroups-per-CU kernel everywhere (tests compare
+// the two; tf_shade_forward_variant)
+int g_forward_variant = 0;
+
+bool pipe_fits(const TfShade& S) {
+    if (S.head != TF_HEAD_MLP || S.feature_c != 128 || kpad16(S.in_c) > 192) return false;
+    return (size_t)pipe_lds(S).total * sizeof(float) <= 160 * 1024 - 512;
+}
+
+int launch_shade_pipe(const TfShade* S, const TileSrc& src, float* rgb_out, int blocks, hipStream_t st, const TfShadeSave& save) {
+    typedef void (*pipe_fn_t)(const TfShade, const TileSrc, float*, const TfShadeSave);
+    pipe_fn_t fn = kpad16(S->in_c) <= 160 ? shade_forward_pipe_kernel<10> : shade_forward_pipe_kernel<12>;
+    const size_t bytes = (size_t)pipe_lds(*S).total * sizeof(float);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(fn), bytes);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(768), bytes, st, *S, src, rgb_out, save);
+    return TF_CHECK_LAUNCH();
+}
+
 }  // namespace
 
 extern "C" {
+
+int tf_shade_forward_variant(int variant) {
+    if (variant < 0 || variant > 1) return (int)hipErrorInvalidValue;
+    g_forward_variant = variant;
+    return 0;
+}
 
 int tf_shade_forward(const TfShade* shade, const float* rays, int ndc, const int* counters, int seg_cap,
                      const int* app_ray, const float* app_xyz, float* rgb_out, int max_workgroups,
@@ -442,6 +797,9 @@ int tf_shade_forward(const TfShade* shade, const float* rays, int ndc, const int
     TileSrc src{counters, seg_cap, 0, app_ray, app_xyz, rays, ndc, nullptr, nullptr};
     const int wgs = max_workgroups > 0 && max_workgroups < 512 ? max_workgroups : 512;
     if (save && shade->head != TF_HEAD_MLP && save->x) return (int)hipErrorInvalidValue;   // X rows exist for MLP heads only
+    if (g_forward_variant == 0 && pipe_fits(*shade))      // one workgroup per CU: half the slots
+        return launch_shade_pipe(shade, src, rgb_out, (wgs + 1) / 2, (hipStream_t)stream,
+                                 save ? *save : TfShadeSave{nullptr, nullptr, nullptr, nullptr});
     return launch_shade(shade, src, rgb_out, nullptr, wgs, (hipStream_t)stream, save ? *save : TfShadeSave{nullptr, nullptr, nullptr, nullptr});
 }
 
@@ -464,6 +822,14 @@ int tf_shade_points(const TfShade* shade, const float* pts_n, const float* viewd
 }
 
 #ifdef TF_PHASE_TIMING
+int tf_debug_phase_cycles_w4(unsigned long long* out16, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(tf_phase_cycles_w4), sizeof(unsigned long long) * 16);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(tf_phase_cycles_w4), z, sizeof(z));
+    }
+    return (int)e;
+}
 int tf_debug_phase_cycles(unsigned long long* out16, int reset) {
     hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(tf_phase_cycles), sizeof(unsigned long long) * 16);
     if (e == hipSuccess && reset) {

@@ -317,6 +317,61 @@ __device__ __forceinline__ bool app_products_lanes8(const TfShade& S, const floa
     return true;
 }
 
+// The same with FOUR lanes per sample and up to three channel quads per lane and plane (components a multiple of 4, at
+// most 48 per plane): the pipelined forward's gather crew is four waves.  All (<= 18) tap pieces of a plane / line pair are
+// requested before the first is used.
+__device__ __forceinline__ bool app_products_lanes4(const TfShade& S, const float u[3], int sub, float* vrow) {
+    if (S.model != TF_MODEL_VM) return false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if ((S.app.n_comp[i] & 3) != 0 || S.app.n_comp[i] > 48) return false;
+    VmTaps t;
+    make_vm_taps(S.grid, u, t);
+    int coff = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int C = S.app.n_comp[i], Q = C >> 2;
+        const float* mk = S.app.mask[i];
+        bool has[3];
+        int q[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            has[j] = sub + 4 * j < Q;
+            q[j] = has[j] ? sub + 4 * j : (Q > sub ? sub : 0);      // (lanes without a quad re-read one: no branch)
+        }
+        float4_t pa[3][4], la[3][2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int ch = q[j] * 4;
+            pa[j][0] = ld4(S.app.plane[i] + (size_t)t.p[i].o00 * C + ch);
+            pa[j][1] = ld4(S.app.plane[i] + (size_t)t.p[i].o01 * C + ch);
+            pa[j][2] = ld4(S.app.plane[i] + (size_t)t.p[i].o10 * C + ch);
+            pa[j][3] = ld4(S.app.plane[i] + (size_t)t.p[i].o11 * C + ch);
+            la[j][0] = ld4(S.app.line[i] + (size_t)t.l[i].o0 * C + ch);
+            la[j][1] = ld4(S.app.line[i] + (size_t)t.l[i].o1 * C + ch);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (!has[j]) continue;
+            const int ch = q[j] * 4;
+            float4_t p, l;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                p[k] = fmaf(pa[j][3][k], t.p[i].w11, fmaf(pa[j][2][k], t.p[i].w10, fmaf(pa[j][1][k], t.p[i].w01, pa[j][0][k] * t.p[i].w00)));
+                l[k] = fmaf(la[j][1][k], t.l[i].w1, la[j][0][k] * t.l[i].w0);
+            }
+            if (mk) {
+                const float4_t m = ld4(mk + ch);
+                p *= m;
+                l *= m;
+            }
+            *reinterpret_cast<float4_t*>(vrow + coff + ch) = p * l;
+        }
+        coff += C;
+    }
+    return true;
+}
+
 // One positional-encoding block of a 64-sample tile written into X (mlp.py:8-13): for every (sample, dim) the F
 // frequencies v*2^k -> sin at x[off + d*F + k], cos at x[off + D*F + d*F + k], times the optional masks.
 // `val(smp, d)` supplies v.  NT threads cooperate.  The F evaluations of an item are independent and evaluated

@@ -211,6 +211,10 @@ typedef struct TfShadeSave {  /* training: rows kept for tf_shade_backward (both
 int tf_shade_forward(const TfShade* shade, const float* rays, int ndc, const int* counters, int seg_cap,
                      const int* app_ray, const float* app_xyz, float* rgb_out, int max_workgroups,
                      const TfShadeSave* save, tf_stream_t stream);
+/* Which kernel tf_shade_forward launches: 0 (default) = the pipelined one-workgroup-per-CU kernel where its conditions
+ * hold (MLP head, feature_c = 128, its LDS layout fits) and the two-workgroups-per-CU kernel elsewhere; 1 = the latter
+ * everywhere.  Process-wide; the parity tests run both. */
+int tf_shade_forward_variant(int variant);
 
 /* rgb_map = sum w*rgb (+ 1-acc when bg) clamped to [0,1]: tensorBase.py:378-384.  rgb_pre (optional)
  * receives the pre-clamp value, which the backward needs for the clamp mask.  n_shaded (optional, with the sharded

@@ -17,19 +17,30 @@ rays = S.blender_rays(1).to(dev)
 perm = torch.randperm(rays.shape[0], generator=torch.Generator().manual_seed(1))[: R * 8].to(dev)
 batches = [rays[perm[i * R:(i + 1) * R]].contiguous() for i in range(8)]
 lib = recon_amd._hip.lib()
+if os.environ.get("TF_FORWARD_CLASSIC"):
+    lib.tf_shade_forward_variant(1)
 out = (ctypes.c_ulonglong * 16)()
-with torch.no_grad():
-    for b in batches:
-        model(b, None, N_samples=N)
-    torch.cuda.synchronize()
-    lib.tf_debug_phase_cycles(out, 1)
-    for b in batches:
-        model(b, None, N_samples=N)
-    torch.cuda.synchronize()
-    lib.tf_debug_phase_cycles(out, 1)
-names = ["info", "gather", "basis+view", "pe", "layer1", "layer2", "out", "locate"]
-tot = sum(out[i] for i in range(8))
+train = len(sys.argv) > 1 and sys.argv[1] == "train"      # training mode: the kernel also writes the saved rows
+with torch.set_grad_enabled(train):
+    for rep in range(2):
+        for b in batches:
+            r = model(b, None, N_samples=N, is_train=train)
+            del r
+        torch.cuda.synchronize()
+        lib.tf_debug_phase_cycles(out, 1)
+print("mode:", "train (V, X, H1, H2 rows saved)" if train else "eval")
 ntile = sum((int(c) + 63) // 64 for c in model.last["ws"].counters2d[:, 0].tolist())
 print("tiles in last batch", ntile)
-for i, n in enumerate(names):
-    print(f"{n:12s} {out[i]/8/ntile:10.0f} cycles/tile  {100*out[i]/tot:5.1f}%")
+if os.environ.get("TF_FORWARD_CLASSIC"):
+    names = ["info", "gather", "basis+view", "pe", "layer1", "layer2", "out", "locate"]
+    tot = sum(out[i] for i in range(8))
+    for i, n in enumerate(names):
+        print(f"{n:12s} {out[i]/8/ntile:10.0f} cycles/tile  {100*out[i]/tot:5.1f}%")
+else:       # the pipelined kernel: work and barrier wait of each phase, per crew (thread 0 / thread 512), per 64-sample chunk
+    out4 = (ctypes.c_ulonglong * 16)()
+    lib.tf_debug_phase_cycles_w4(out4, 1)
+    names = ["phase 1 work", "phase 1 wait", "phase 2 work", "phase 2 wait", "phase 3 work", "phase 3 wait"]
+    print(f"{'':14s} {'MLP crew':>12s} {'front crew':>12s}   cycles / chunk")
+    for i, n in enumerate(names):
+        print(f"{n:14s} {out[i]/8/ntile:12.0f} {out4[i]/8/ntile:12.0f}")
+    print(f"{'total':14s} {sum(out[:6])/8/ntile:12.0f} {sum(out4[:6])/8/ntile:12.0f}")
