@@ -400,17 +400,18 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
 // weights, biases, W3, b3), and on a CU whose memory pipe is busy with the other workgroup's gather (~220 KB per chunk at
 // 11-18 B/cycle) every one of them queues behind that traffic: 65 k cycles per chunk and CU for 22 k cycles of MFMA
 // issue.  Here ONE 768-thread workgroup owns the CU and its 12 waves (three per SIMD: 168 VGPRs) are two crews working on
-// consecutive chunks:
-//   waves 0..7  (MLP crew)    chunk c:      B1  X -> H1         B2  H1 -> H2            B3  (training: H1 / H2 rows out)
-//   waves 8..11 (front crew)  chunk c + 1:  F1  gather -> V     F2  basis, view -> X'   F3  encodings -> X'; output layer of c
-// in lock step (three LDS-only barriers per iteration; s_barrier counts waves, whichever instruction they arrive at).  The
-// MLP crew keeps its slice of W1 and W2 (one 16-feature tile per wave, 72-80 VGPRs) and the biases in registers for the
-// whole launch and never waits for global memory; the gather, the only bulk fetch, runs beside the hidden layers'
-// MFMAs instead of in front of them.  LDS: X double-buffered (H2 overlays the X of its own chunk), V, H1 — 155.9 KB at
-// config 2.  Shapes that do not fit (or other heads / hidden widths) use the kernel above.
+// consecutive chunks, in lock step through five LDS-only barriers per iteration (s_barrier counts waves, whichever
+// instruction they arrive at):
+//   waves 0..7  (MLP crew),   chunk c:   P1 basis, view -> X   P2 encodings -> X   P3 X -> H1   P4 H1 -> H2   P5 rows out
+//   waves 8..11 (gather crew), chunk c + 1: the nine (plane, channel-quad) units of the appearance gather -> V', dealt
+//                             1 / 2 / 3 / 3 / 0 over the five phases; in P5 the output layer of chunk c (W3 resident)
+// The MLP crew keeps its slice of W1, W2 and the basis (one 16-feature tile per wave, <= 124 VGPRs) and the biases in
+// registers for the whole launch and never waits for global memory; the gather — the only bulk fetch — runs beside
+// everything else instead of in front of it.  LDS: X (H2 overlays it), H1, V and the sample info double-buffered — 155.3 KB
+// at config 2.  Shapes that do not fit (or other heads / hidden widths) use the kernel above.
 struct PipeLds {
     int sv, sx, sh, xw;
-    int offX0, offX1, offV, offH1, offInfo, offPre, total;
+    int offX, offH1, offV0, offV1, offInfo0, offInfo1, offPre, total;
 };
 __host__ __device__ inline PipeLds pipe_lds(const TfShade& S) {
     PipeLds L;
@@ -418,27 +419,84 @@ __host__ __device__ inline PipeLds pipe_lds(const TfShade& S) {
     L.sx = kpad16(S.in_c) + 4;
     L.sh = S.feature_c + 4;
     L.xw = L.sx > L.sh ? L.sx : L.sh;
-    L.offX0 = 0;
-    L.offX1 = M * L.xw;
-    L.offV = 2 * M * L.xw;
-    L.offH1 = L.offV + M * L.sv;
-    L.offInfo = L.offH1 + M * L.sh;
-    L.offPre = L.offInfo + M * 6;
+    L.offX = 0;
+    L.offH1 = M * L.xw;
+    L.offV0 = L.offH1 + M * L.sh;
+    L.offV1 = L.offV0 + M * L.sv;
+    L.offInfo0 = L.offV1 + M * L.sv;
+    L.offInfo1 = L.offInfo0 + M * 6;
+    L.offPre = L.offInfo1 + M * 6;
     L.total = L.offPre + 68;
     return L;
 }
 
+#ifdef TF_PHASE_TIMING
+#define TF_ABL(bit) (tf_dbg_flags & (bit))      // diagnostic build: 4 = no gather, 8 = no hidden-layer MFMAs, 16 = no basis / encodings
+#else
+#define TF_ABL(bit) 0
+#endif
 #ifdef TF_PHASE_TIMING
 #define TF_PIPE_FLUSH(first_thread, arr) do { if ((int)threadIdx.x == (first_thread)) for (int _i = 0; _i < 16; ++_i) atomicAdd(&arr[_i], _ph[_i]); } while (0)
 #else
 #define TF_PIPE_FLUSH(first_thread, arr)
 #endif
 
+// Units [U0, U0 + NU) of the appearance gather of one sample, by lane `sub` of its four: unit u = plane u / 3, channel quad
+// sub + 4 (u % 3) (components a multiple of 4 and <= 48 per plane: pipe_gather_ok).  All 6 NU tap pieces are requested
+// before the first is used; the products (P m)(L m) go to vrow (tensoRF.py:238-260).
+template <int U0, int NU>
+__device__ __forceinline__ void gather_units(const TfShade& S, const VmTaps& t, int sub, float* vrow) {
+    float4_t pa[NU][4], la[NU][2];
+    bool has[NU];
+    int ch[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+        const int i = (U0 + k) / 3, j = (U0 + k) % 3;
+        const int C = S.app.n_comp[i], Q = C >> 2;
+        has[k] = sub + 4 * j < Q;
+        ch[k] = 4 * (has[k] ? sub + 4 * j : (Q > sub ? sub : 0));      // (lanes without a quad re-read one: no branch)
+        pa[k][0] = ld4(S.app.plane[i] + (size_t)t.p[i].o00 * C + ch[k]);
+        pa[k][1] = ld4(S.app.plane[i] + (size_t)t.p[i].o01 * C + ch[k]);
+        pa[k][2] = ld4(S.app.plane[i] + (size_t)t.p[i].o10 * C + ch[k]);
+        pa[k][3] = ld4(S.app.plane[i] + (size_t)t.p[i].o11 * C + ch[k]);
+        la[k][0] = ld4(S.app.line[i] + (size_t)t.l[i].o0 * C + ch[k]);
+        la[k][1] = ld4(S.app.line[i] + (size_t)t.l[i].o1 * C + ch[k]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+        const int i = (U0 + k) / 3;
+        if (!has[k]) continue;
+        const int coff = i == 0 ? 0 : (i == 1 ? S.app.n_comp[0] : S.app.n_comp[0] + S.app.n_comp[1]);
+        float4_t p, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            p[e] = fmaf(pa[k][3][e], t.p[i].w11, fmaf(pa[k][2][e], t.p[i].w10, fmaf(pa[k][1][e], t.p[i].w01, pa[k][0][e] * t.p[i].w00)));
+            l[e] = fmaf(la[k][1][e], t.l[i].w1, la[k][0][e] * t.l[i].w0);
+        }
+        const float* mk = S.app.mask[i];
+        if (mk) {
+            const float4_t m = ld4(mk + ch[k]);
+            p *= m;
+            l *= m;
+        }
+        *reinterpret_cast<float4_t*>(vrow + coff + ch[k]) = p * l;
+    }
+}
+__host__ __device__ inline bool pipe_gather_ok(const TfShade& S) {
+    if (S.model != TF_MODEL_VM) return false;
+    for (int i = 0; i < 3; ++i)
+        if ((S.app.n_comp[i] & 3) != 0 || S.app.n_comp[i] > 48) return false;
+    return true;
+}
+
+// KT1: k-groups of layer 1 held in registers (10: in_c <= 160, with the basis fragments resident as well; 12: in_c <= 192)
 template <int KT1>
 __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S, const TileSrc src, float* __restrict__ rgb_out,
-                                                                  const TfShadeSave save) {
+                                                                 const TfShadeSave save) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NC = 512, NCF = 256, FT = 8;       // threads of the MLP / front crew; feature tiles (feature_c = 128)
+    constexpr int NC = 512, FT = 8;       // threads of the MLP crew (the gather crew has 256); feature tiles (feature_c = 128)
+    constexpr int KTB = 9;                           // basis k-groups that can stay in registers (n_app_total <= 144)
     const PipeLds L = pipe_lds(S);
     int* pre = reinterpret_cast<int*>(lds + L.offPre);
     if (threadIdx.x == 0) {
@@ -456,19 +514,25 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
     const int v_end = min(total, (int)((((long long)blockIdx.x + 1) * n_tiles) / (long long)gridDim.x) * 16);
     // (a chunk is cut short where it would span a third shard — fwd_locate — so the chunk sequence is walked, not
     // computed: both crews walk it alike, the MLP crew one chunk behind)
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    int tid0 = threadIdx.x;
+    asm volatile("" : "+v"(tid0));
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int kp1 = kpad16(S.in_c), kt1 = kp1 / 16;
+    const int nb = (S.app_dim + 15) >> 4, ktb = kpad16(S.n_app_total) / 16;
+    float* X = lds + L.offX;
     float* H1 = lds + L.offH1;
     TF_T0();
 
     if (wave < 8) {
-        // ================= MLP crew: chunk it - 1 =================
-        const int f_base = 16 * wave, lg0 = lane >> 4;
-        f32x4 fr1[KT1][1], fr2[FT][1];
-        load_a_frags<1, KT1>(S.w1, kp1, f_base, kt1, lane, fr1);
-        load_a_frags<1, FT>(S.w2, 16 * FT, f_base, FT, lane, fr2);
+        // ================= MLP crew =================
+        const int f_base = 16 * wave, lane0 = tid0 & 63, lg0 = lane0 >> 4;
+        const bool basis_resident = KT1 <= 10 && nb <= 2 && ktb <= KTB;      // one (feature tile, sample tile) pair per wave
+        f32x4 fr1[KT1][1], fr2[FT][1], frb[KT1 <= 10 ? KTB : 1][1];
+        load_a_frags<1, KT1>(S.w1, kp1, f_base, kt1, lane0, fr1);
+        load_a_frags<1, FT>(S.w2, 16 * FT, f_base, FT, lane0, fr2);
+        if constexpr (KT1 <= 10) {
+            if (basis_resident && wave < 4 * nb) load_a_frags<1, KTB>(S.basis, 16 * ktb, 16 * (wave >> 2), ktb, lane0, frb);
+        }
         const f32x4 bias1 = *reinterpret_cast<const f32x4*>(S.b1 + f_base + 4 * lg0);
         const f32x4 bias2 = *reinterpret_cast<const f32x4*>(S.b2 + f_base + 4 * lg0);
         FChunk ck;
@@ -481,19 +545,84 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));
             const int lane = tid & 63, lc = lane & 15, lg = lane >> 4;
-            FChunk ck_front;
-            const bool more = fwd_locate(src, pre, v, v_end, ck_front);      // the front crew's chunk of this iteration
-            v += ck_front.n();
-            const int n = on ? ck.n() : 0, nt = (n + 15) >> 4;
-            float* X = lds + (par ? L.offX0 : L.offX1);      // the buffer the front crew filled in the previous iteration
+            FChunk ck_next;
+            const bool more = fwd_locate(src, pre, v, v_end, ck_next);      // the gather crew's chunk of this iteration
+            v += ck_next.n();
+            const int n = on ? ck.n() : 0, nt = (n + 15) >> 4, n16 = 16 * nt;
+            const float* V = lds + (par ? L.offV0 : L.offV1);               // filled during the previous iteration
+            const float* ixyz = lds + (par ? L.offInfo0 : L.offInfo1);
+            const float* iview = ixyz + 3 * M;
             auto at = [&](int r) { return ck.at(r); };
-            // ---- B1: H1 = relu(W1 X + b1)
+            // ---- P1: feat = B V^T -> X, view columns
+            if (on && !TF_ABL(16)) {
+                for (int pr = wave; pr < 4 * nb; pr += 8) {
+                    const int bf = pr >> 2, bs = pr & 3;
+                    if (bs >= nt) continue;
+                    f32x4 acc[1][1];
+                    acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    bool done = false;
+                    if constexpr (KT1 <= 10) {
+                        if (basis_resident) {
+                            mma_frags<1, 1, KTB>(frb, V, L.sv, 16 * bs, ktb, acc, lane);
+                            done = true;
+                        }
+                    }
+                    if (!done) mma_block<1, 1>(S.basis, 16 * ktb, 16 * bf, V, L.sv, 16 * bs, ktb, acc, lane);
+                    const int row = 16 * bs + lc;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int f = 16 * bf + 4 * lg + e;
+                        if (f < S.app_dim) X[row * L.sx + f] = acc[0][0][e];
+                    }
+                }
+                if (tid < M) {
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) X[tid * L.sx + S.app_dim + a] = iview[tid * 3 + a];
+                }
+            }
+            TF_MARK(0);
+            lds_barrier();
+            TF_MARK(1);
+            // ---- P2: positional-encoding blocks + zero K padding  (training rows leave phase by phase, each behind the
+            // barrier that completes it, so that the stores drain under the next phase's arithmetic)
+            if (on) {
+                if (save.v) {
+                    const int nat = S.n_app_total;
+                    if ((nat & 3) == 0) {
+                        save_rows<NC>(save.v, V, L.sv, nat, n, tid, at);
+                    } else {
+                        for (int r = wave; r < n; r += 8)
+                            for (int c = lane; c < nat; c += 64) save.v[ck.at(r) * nat + c] = V[r * L.sv + c];
+                    }
+                }
+                int off = S.app_dim + 3;
+                for (int b = 0; b < (TF_ABL(16) ? 0 : S.n_pe); ++b) {
+                    const int src_k = S.pe[b].src, F = S.pe[b].freqs;
+                    const int D = src_k == TF_SRC_FEAT ? S.app_dim : 3;
+                    const float* mk = S.pe[b].mask;
+                    const float* xb = X;
+                    const int sx = L.sx;
+                    pe_block<NC>(X, L.sx, off, D, F, mk, tid, [&](int s_, int d) {
+                        return src_k == TF_SRC_FEAT ? xb[s_ * sx + d] : (src_k == TF_SRC_VIEW ? iview[s_ * 3 + d] : ixyz[s_ * 3 + d]);
+                    }, n16);
+                    off += 2 * D * F;
+                }
+                for (int i2 = tid; i2 < n16 * 16; i2 += NC) {     // the K padding is < 16 columns
+                    const int s_ = i2 >> 4, c = S.in_c + (i2 & 15);
+                    if (c < kp1) X[s_ * L.sx + c] = 0.f;
+                }
+            }
+            TF_MARK(2);
+            lds_barrier();
+            TF_MARK(3);
+            // ---- P3: H1 = relu(W1 X + b1)
             if (on) {
                 if (save.x) save_rows<NC>(save.x, X, L.sx, kp1, n, tid, at);
                 f32x4 acc[1][4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (nt > 2) mma_frags<1, 4, KT1>(fr1, X, L.sx, 0, kt1, acc, lane);
+                if (TF_ABL(8)) {}
+                else if (nt > 2) mma_frags<1, 4, KT1>(fr1, X, L.sx, 0, kt1, acc, lane);
                 else mma_frags<1, 2, KT1>(fr1, X, L.sx, 0, kt1, reinterpret_cast<f32x4 (&)[1][2]>(acc), lane);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -504,15 +633,17 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
                     *reinterpret_cast<f32x4*>(H1 + (16 * j + lc) * L.sh + f_base + 4 * lg) = h;
                 }
             }
-            TF_MARK(0);
+            TF_MARK(4);
             lds_barrier();
-            TF_MARK(1);
-            // ---- B2: H2 = relu(W2 H1 + b2), written over this chunk's X
+            TF_MARK(5);
+            // ---- P4: H2 = relu(W2 H1 + b2), written over X
             if (on) {
+                if (save.h1) save_rows<NC>(save.h1, H1, L.sh, 16 * FT, n, tid, at);
                 f32x4 acc[1][4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (nt > 2) mma_frags<1, 4, FT>(fr2, H1, L.sh, 0, FT, acc, lane);
+                if (TF_ABL(8)) {}
+                else if (nt > 2) mma_frags<1, 4, FT>(fr2, H1, L.sh, 0, FT, acc, lane);
                 else mma_frags<1, 2, FT>(fr2, H1, L.sh, 0, FT, reinterpret_cast<f32x4 (&)[1][2]>(acc), lane);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -523,31 +654,35 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
                     *reinterpret_cast<f32x4*>(X + (16 * j + lc) * L.sh + f_base + 4 * lg) = h;
                 }
             }
-            TF_MARK(2);
+            TF_MARK(6);
             lds_barrier();
-            TF_MARK(3);
-            // ---- B3: training rows
-            if (on) {
-                if (save.h1) save_rows<NC>(save.h1, H1, L.sh, 16 * FT, n, tid, at);
-                if (save.h2) save_rows<NC>(save.h2, X, L.sh, 16 * FT, n, tid, at);
-            }
-            TF_MARK(4);
+            TF_MARK(7);
+            // ---- P5: training rows (the gather crew runs the output layer)
+            if (on && save.h2) save_rows<NC>(save.h2, X, L.sh, 16 * FT, n, tid, at);
+            TF_MARK(8);
             lds_barrier();
-            TF_MARK(5);
+            TF_MARK(9);
             if (!more) break;
-            ck = ck_front;
+            ck = ck_next;
             on = true;
         }
         TF_PIPE_FLUSH(0, tf_phase_cycles);
     } else {
-        // ================= front crew: chunk it (and the output layer of chunk it - 1) =================
+        // ================= gather crew: chunk of this iteration; output layer of the previous one =================
         const int fw = wave - 8;
-        float* V = lds + L.offV;
-        float* ixyz = lds + L.offInfo;
-        float* iview = lds + L.offInfo + 3 * M;
+        const bool quads = pipe_gather_ok(S);
         const float b3[3] = {S.b3[0], S.b3[1], S.b3[2]};
+        f32x4 fr3[FT];      // W3 as rows 0..2 of a 16-row operand tile (the other rows zero), for the whole launch
+        {
+            const int lc0 = tid0 & 15, lg0 = (tid0 & 63) >> 4, r3 = lc0 < 3 ? lc0 : 2;
+#pragma unroll
+            for (int k = 0; k < FT; ++k) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(S.w3 + r3 * (16 * FT) + 16 * k + 4 * lg0);
+                fr3[k] = lc0 < 3 ? w : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
         // per-sample info, requested one iteration ahead: every lane of a sample's 4 holds its coordinates, lane 0 of the 4
-        // its view direction (app_ray -> rays: the second load is issued a phase later, when the first has arrived)
+        // its ray index, then its view direction (app_ray -> rays: the second load goes out a phase after the first)
         float nx_x[3] = {0.f, 0.f, 0.f}, nx_v[3] = {0.f, 0.f, 0.f};
         int nx_ray = -1;
         auto fetch_xyz = [&](const FChunk& c, int smp, int sub) {
@@ -570,10 +705,7 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
         };
         {
             FChunk c0;
-            if (fwd_locate(src, pre, v_begin, v_end, c0)) {
-                fetch_xyz(c0, (tid - NC) >> 2, tid & 3);
-                fetch_view();
-            }
+            if (fwd_locate(src, pre, v_begin, v_end, c0)) fetch_xyz(c0, (tid0 - NC) >> 2, tid0 & 3);
         }
         FChunk ckm;
         ckm.s0 = ckm.n0 = ckm.s1 = ckm.n1 = 0;
@@ -587,115 +719,68 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
             FChunk ckf;
             const bool on_f = fwd_locate(src, pre, v, v_end, ckf);
             v += ckf.n();
-            const int nf = on_f ? ckf.n() : 0, ntf = (nf + 15) >> 4, n16f = 16 * ntf;
+            const int nf = on_f ? ckf.n() : 0, n16f = 16 * ((nf + 15) >> 4);
             const int nm = on_m ? ckm.n() : 0, ntm = (nm + 15) >> 4;
-            float* Xf = lds + (par ? L.offX1 : L.offX0);
-            const float* Xm = lds + (par ? L.offX0 : L.offX1);      // holds H2 of the previous chunk by phase 3
-            // ---- F1: sample info -> LDS, appearance gather -> V
-            if (on_f) {
-                if (sub == 0) {
-                    if (src.ndc && smp < nf) {   // viewdirs / rays_norm  (tensorBase.py:341-343)
-                        float q = nx_v[0] * nx_v[0];
-                        q = q + nx_v[1] * nx_v[1];
-                        q = q + nx_v[2] * nx_v[2];
-                        const float nrm = sqrtf(q);
-                        nx_v[0] = nx_v[0] / nrm; nx_v[1] = nx_v[1] / nrm; nx_v[2] = nx_v[2] / nrm;
-                    }
+            float* V = lds + (par ? L.offV1 : L.offV0);
+            float* ixyz = lds + (par ? L.offInfo1 : L.offInfo0);
+            float* iview = ixyz + 3 * M;
+            float* vrow = V + smp * L.sv;
+            const bool row_on = on_f && smp < n16f && !TF_ABL(4);
+            const float u[3] = {nx_x[0], nx_x[1], nx_x[2]};
+            VmTaps t;
+            make_vm_taps(S.grid, u, t);
+            // ---- P1: unit 0; coordinates -> LDS; the view direction's request
+            fetch_view();
+            if (on_f && sub == 0) {
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        ixyz[smp * 3 + a] = nx_x[a];
-                        iview[smp * 3 + a] = nx_v[a];
-                    }
-                }
-                if (smp < n16f) {
-                    const float u[3] = {nx_x[0], nx_x[1], nx_x[2]};
-                    float* vrow = V + smp * L.sv;
-                    if (!app_products_lanes4(S, u, sub, vrow)) app_products(S, u, sub, vrow, 4);
-                    for (int c = S.n_app_total + sub; c < kpad16(S.n_app_total); c += 4) vrow[c] = 0.f;
-                }
+                for (int a = 0; a < 3; ++a) ixyz[smp * 3 + a] = nx_x[a];
+            }
+            if (row_on) {
+                if (quads) gather_units<0, 1>(S, t, sub, vrow);
+                for (int c = S.n_app_total + sub; c < kpad16(S.n_app_total); c += 4) vrow[c] = 0.f;
             }
             TF_MARK(0);
             lds_barrier();
             TF_MARK(1);
-            // ---- F2: basis -> feat columns of X', view columns, training rows of V
-            if (on_f) {
-                const int nb = (S.app_dim + 15) >> 4, ktb = kpad16(S.n_app_total) / 16;
-                for (int pr = fw; pr < 4 * nb; pr += 4) {
-                    const int bf = pr >> 2, bs = pr & 3;
-                    if (bs >= ntf) continue;
-                    f32x4 acc[1][1];
-                    acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (ktb <= 9) {      // all weight fragments of the product requested at once
-                        f32x4 frb[9][1];
-                        load_a_frags<1, 9>(S.basis, 16 * ktb, 16 * bf, ktb, lane, frb);
-                        mma_frags<1, 1, 9>(frb, V, L.sv, 16 * bs, ktb, acc, lane);
-                    } else {
-                        mma_block<1, 1>(S.basis, 16 * ktb, 16 * bf, V, L.sv, 16 * bs, ktb, acc, lane);
-                    }
-                    const int row = 16 * bs + lc;
+            // ---- P2: units 1, 2; view direction -> LDS
+            if (on_f && sub == 0) {
+                if (src.ndc && smp < nf) {   // viewdirs / rays_norm  (tensorBase.py:341-343)
+                    float q = nx_v[0] * nx_v[0];
+                    q = q + nx_v[1] * nx_v[1];
+                    q = q + nx_v[2] * nx_v[2];
+                    const float nrm = sqrtf(q);
+                    nx_v[0] = nx_v[0] / nrm; nx_v[1] = nx_v[1] / nrm; nx_v[2] = nx_v[2] / nrm;
+                }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int f = 16 * bf + 4 * lg + e;
-                        if (f < S.app_dim) Xf[row * L.sx + f] = acc[0][0][e];
-                    }
-                }
-                if (ftid < M) {
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) Xf[ftid * L.sx + S.app_dim + a] = iview[ftid * 3 + a];
-                }
-                if (save.v) {
-                    const int nat = S.n_app_total;
-                    auto atf = [&](int r) { return ckf.at(r); };
-                    if ((nat & 3) == 0) {
-                        save_rows<NCF>(save.v, V, L.sv, nat, nf, ftid, atf);
-                    } else {
-                        for (int r = fw; r < nf; r += 4)
-                            for (int c = lane; c < nat; c += 64) save.v[ckf.at(r) * nat + c] = V[r * L.sv + c];
-                    }
-                }
+                for (int a = 0; a < 3; ++a) iview[smp * 3 + a] = nx_v[a];
             }
+            if (row_on && quads) gather_units<1, 2>(S, t, sub, vrow);
             TF_MARK(2);
             lds_barrier();
             TF_MARK(3);
-            // ---- F3: requests for later (next chunk's coordinates, W3), encodings of X', output layer of chunk it - 1
+            // ---- P3: units 3..5 (other field shapes: the whole row, tap by tap)
+            if (row_on) {
+                if (quads) gather_units<3, 3>(S, t, sub, vrow);
+                else app_products(S, u, sub, vrow, 4);
+            }
+            TF_MARK(4);
+            lds_barrier();
+            TF_MARK(5);
+            // ---- P4: units 6..8
+            if (row_on && quads) gather_units<6, 3>(S, t, sub, vrow);
+            TF_MARK(6);
+            lds_barrier();
+            TF_MARK(7);
+            // ---- P5: the next chunk's coordinates (requests only); output layer of the previous chunk (its H2 lies in X)
             {
                 FChunk c1;
                 nx_ray = -1;
                 if (on_f && fwd_locate(src, pre, v, v_end, c1)) fetch_xyz(c1, smp, sub);
                 else { nx_x[0] = nx_x[1] = nx_x[2] = 0.f; }
             }
-            f32x4 fr3[FT];
-            if (fw < ntm) {
-                const int r3 = lc < 3 ? lc : 2;
-#pragma unroll
-                for (int k = 0; k < FT; ++k) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(S.w3 + r3 * (16 * FT) + 16 * k + 4 * lg);
-                    fr3[k] = lc < 3 ? w : (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (on_f) {
-                int off = S.app_dim + 3;
-                for (int b = 0; b < S.n_pe; ++b) {
-                    const int src_k = S.pe[b].src, F = S.pe[b].freqs;
-                    const int D = src_k == TF_SRC_FEAT ? S.app_dim : 3;
-                    const float* mk = S.pe[b].mask;
-                    const float* xb = Xf;
-                    const int sx = L.sx;
-                    pe_block<NCF>(Xf, L.sx, off, D, F, mk, ftid, [&](int s_, int d) {
-                        return src_k == TF_SRC_FEAT ? xb[s_ * sx + d] : (src_k == TF_SRC_VIEW ? iview[s_ * 3 + d] : ixyz[s_ * 3 + d]);
-                    }, n16f);
-                    off += 2 * D * F;
-                }
-                for (int i2 = ftid; i2 < n16f * 16; i2 += NCF) {     // the K padding is < 16 columns
-                    const int s_ = i2 >> 4, c = S.in_c + (i2 & 15);
-                    if (c < kp1) Xf[s_ * L.sx + c] = 0.f;
-                }
-            }
-            fetch_view();       // (the ray index asked for above has arrived behind the encodings)
             if (fw < ntm) {     // o[c][s] = sum_f W3[c][f] H2[s][f]; W3 as rows 0..2 of a 16-row operand tile
                 f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                const float* xp = Xm + (16 * fw + lc) * L.sh + 4 * lg;
+                const float* xp = X + (16 * fw + lc) * L.sh + 4 * lg;
 #pragma unroll
                 for (int k = 0; k < FT; ++k) {
                     const f32x4 b = *reinterpret_cast<const f32x4*>(xp + 16 * k);
@@ -714,9 +799,9 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
                     o[2] = 1.f / (1.f + expf(-(acc[2] + b3[2])));
                 }
             }
-            TF_MARK(4);
+            TF_MARK(8);
             lds_barrier();
-            TF_MARK(5);
+            TF_MARK(9);
             if (!on_f) break;
             ckm = ckf;
             on_m = true;
@@ -822,6 +907,7 @@ int tf_shade_points(const TfShade* shade, const float* pts_n, const float* viewd
 }
 
 #ifdef TF_PHASE_TIMING
+int tf_debug_set_flags_fwd(int flags) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(tf_dbg_flags), &flags, sizeof(int)); }
 int tf_debug_phase_cycles_w4(unsigned long long* out16, int reset) {
     hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(tf_phase_cycles_w4), sizeof(unsigned long long) * 16);
     if (e == hipSuccess && reset) {

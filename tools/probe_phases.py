@@ -19,6 +19,9 @@ batches = [rays[perm[i * R:(i + 1) * R]].contiguous() for i in range(8)]
 lib = recon_amd._hip.lib()
 if os.environ.get("TF_FORWARD_CLASSIC"):
     lib.tf_shade_forward_variant(1)
+if os.environ.get("TF_ABLATE"):      # timing only (results are wrong): 4 = no gather, 8 = no hidden-layer MFMAs, 16 = no basis / encodings
+    lib.tf_debug_set_flags_fwd(int(os.environ["TF_ABLATE"]))
+    print("ablation flags", os.environ["TF_ABLATE"])
 out = (ctypes.c_ulonglong * 16)()
 train = len(sys.argv) > 1 and sys.argv[1] == "train"      # training mode: the kernel also writes the saved rows
 with torch.set_grad_enabled(train):
@@ -28,6 +31,8 @@ with torch.set_grad_enabled(train):
             del r
         torch.cuda.synchronize()
         lib.tf_debug_phase_cycles(out, 1)
+        if rep == 0:
+            lib.tf_debug_phase_cycles_w4((ctypes.c_ulonglong * 16)(), 1)
 print("mode:", "train (V, X, H1, H2 rows saved)" if train else "eval")
 ntile = sum((int(c) + 63) // 64 for c in model.last["ws"].counters2d[:, 0].tolist())
 print("tiles in last batch", ntile)
@@ -39,8 +44,8 @@ if os.environ.get("TF_FORWARD_CLASSIC"):
 else:       # the pipelined kernel: work and barrier wait of each phase, per crew (thread 0 / thread 512), per 64-sample chunk
     out4 = (ctypes.c_ulonglong * 16)()
     lib.tf_debug_phase_cycles_w4(out4, 1)
-    names = ["phase 1 work", "phase 1 wait", "phase 2 work", "phase 2 wait", "phase 3 work", "phase 3 wait"]
+    names = [f"phase {k + 1} {w}" for k in range(5) for w in ("work", "wait")]
     print(f"{'':14s} {'MLP crew':>12s} {'front crew':>12s}   cycles / chunk")
     for i, n in enumerate(names):
         print(f"{n:14s} {out[i]/8/ntile:12.0f} {out4[i]/8/ntile:12.0f}")
-    print(f"{'total':14s} {sum(out[:6])/8/ntile:12.0f} {sum(out4[:6])/8/ntile:12.0f}")
+    print(f"{'total':14s} {sum(out[:10])/8/ntile:12.0f} {sum(out4[:10])/8/ntile:12.0f}")
