@@ -402,37 +402,44 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
 // issue.  Here ONE 768-thread workgroup owns the CU and its 12 waves (three per SIMD: 168 VGPRs) are two crews working on
 // consecutive chunks, in lock step through five LDS-only barriers per iteration (s_barrier counts waves, whichever
 // instruction they arrive at):
-//   waves 0..7  (MLP crew),   chunk c:   P1 basis, view -> X   P2 encodings -> X   P3 X -> H1   P4 H1 -> H2   P5 rows out
+//   waves 0..7  (MLP crew),   chunk c:   P1 basis, view -> X   P2 encodings -> X   P3 X -> H1   P4 H1 -> H2, W3 partials
+//                                        P5 output layer's sum + sigmoid
 //   waves 8..11 (gather crew), chunk c + 1: the nine (plane, channel-quad) units of the appearance gather -> V', dealt
-//                             1 / 2 / 3 / 3 / 0 over the five phases; in P5 the output layer of chunk c (W3 resident)
-// The MLP crew keeps its slice of W1, W2 and the basis (one 16-feature tile per wave, <= 124 VGPRs) and the biases in
+//                             1 / 2 / 3 / 3 / 0 over the phases; coordinates and view directions of chunk c + 2
+// The MLP crew keeps its slice of W1, W2 and the basis (one 16-feature tile per wave, 108 VGPRs) and the biases in
 // registers for the whole launch and never waits for global memory; the gather — the only bulk fetch — runs beside
-// everything else instead of in front of it.  LDS: X (H2 overlays it), H1, V and the sample info double-buffered — 155.3 KB
-// at config 2.  Shapes that do not fit (or other heads / hidden widths) use the kernel above.
+// everything else instead of in front of it; nothing on either crew's path waits for a load it has just issued.  LDS: X
+// (H2 overlays it), H1, V and the sample info double-buffered, W3 — 157 KB.  The k extents are the template's (10 / 9 / 8
+// k-groups: in_c <= 160, n_app_total <= 144): shorter operands are zero padded, the MFMA loops carry no guards.  Shapes
+// beyond that (or other heads / hidden widths) use the kernel above.
+constexpr int PIPE_KT1 = 10, PIPE_KTB = 9, PIPE_FT = 8;
 struct PipeLds {
-    int sv, sx, sh, xw;
-    int offX, offH1, offV0, offV1, offInfo0, offInfo1, offPre, total;
+    int sv, sx, sh;
+    int offX, offH1, offV0, offV1, offInfo0, offInfo1, offW3, offDesc, offPre, total;
 };
-__host__ __device__ inline PipeLds pipe_lds(const TfShade& S) {
+__host__ __device__ inline PipeLds pipe_lds() {
     PipeLds L;
-    L.sv = kpad16(S.n_app_total) + 4;
-    L.sx = kpad16(S.in_c) + 4;
-    L.sh = S.feature_c + 4;
-    L.xw = L.sx > L.sh ? L.sx : L.sh;
+    L.sv = 16 * PIPE_KTB + 4;
+    L.sx = 16 * PIPE_KT1 + 4;
+    L.sh = 16 * PIPE_FT + 4;
     L.offX = 0;
-    L.offH1 = M * L.xw;
+    L.offH1 = M * L.sx;
     L.offV0 = L.offH1 + M * L.sh;
     L.offV1 = L.offV0 + M * L.sv;
     L.offInfo0 = L.offV1 + M * L.sv;
     L.offInfo1 = L.offInfo0 + M * 6;
-    L.offPre = L.offInfo1 + M * 6;
+    L.offW3 = L.offInfo1 + M * 6;
+    L.offDesc = L.offW3 + 3 * 16 * PIPE_FT;      // ring of 4 chunk descriptors (FChunk), written by the gather crew
+    L.offPre = L.offDesc + 16;
     L.total = L.offPre + 68;
     return L;
 }
 
-#ifdef TF_PHASE_TIMING
-#define TF_ABL(bit) (tf_dbg_flags & (bit))      // diagnostic build: 4 = no gather, 8 = no hidden-layer MFMAs, 16 = no basis / encodings
+#ifdef TF_PHASE_TIMING      // diagnostic build: 4 = no gather, 8 = no hidden-layer MFMAs, 16 = no basis / encodings (timing only)
+#define TF_ABL_INIT() const int abl_ = __builtin_amdgcn_readfirstlane(tf_dbg_flags)
+#define TF_ABL(bit) (abl_ & (bit))
 #else
+#define TF_ABL_INIT()
 #define TF_ABL(bit) 0
 #endif
 #ifdef TF_PHASE_TIMING
@@ -489,16 +496,33 @@ __host__ __device__ inline bool pipe_gather_ok(const TfShade& S) {
         if ((S.app.n_comp[i] & 3) != 0 || S.app.n_comp[i] > 48) return false;
     return true;
 }
+// weight fragments of a wave's feature tile for the whole launch; k-groups past the matrix are ZERO (the operand tiles in
+// LDS are padded with zeros to the template's extent, so the products there are 0 x 0)
+typedef int int4_desc __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ FChunk desc_chunk(const int4_desc d) {      // wave-uniform copy (the fields index LDS / global rows)
+    FChunk c;
+    c.s0 = __builtin_amdgcn_readfirstlane(d[0]);
+    c.n0 = __builtin_amdgcn_readfirstlane(d[1]);
+    c.s1 = __builtin_amdgcn_readfirstlane(d[2]);
+    c.n1 = __builtin_amdgcn_readfirstlane(d[3]);
+    return c;
+}
+template <int KG>
+__device__ __forceinline__ void load_resident_frags(const float* __restrict__ Wg, int ldw, int f_base, int kgroups, int lane,
+                                                    f32x4 (&a)[KG][1]) {
+    load_a_frags<1, KG>(Wg, ldw, f_base, kgroups > 0 ? kgroups : 1, lane, a);
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg)
+        if (kg >= kgroups) a[kg][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
 
-// KT1: k-groups of layer 1 held in registers (10: in_c <= 160, with the basis fragments resident as well; 12: in_c <= 192)
-template <int KT1>
 __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S, const TileSrc src, float* __restrict__ rgb_out,
                                                                  const TfShadeSave save) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NC = 512, FT = 8;       // threads of the MLP crew (the gather crew has 256); feature tiles (feature_c = 128)
-    constexpr int KTB = 9;                           // basis k-groups that can stay in registers (n_app_total <= 144)
-    const PipeLds L = pipe_lds(S);
+    constexpr int NC = 512, KT1 = PIPE_KT1, KTB = PIPE_KTB, FT = PIPE_FT, FC = 16 * PIPE_FT;
+    const PipeLds L = pipe_lds();
     int* pre = reinterpret_cast<int*>(lds + L.offPre);
+    float* w3s = lds + L.offW3;                      // [3][128]
     if (threadIdx.x == 0) {
         int run = 0;
         for (int g = 0; g < TF_N_SHARDS; ++g) {
@@ -507,13 +531,16 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
         }
         pre[TF_N_SHARDS] = run;
     }
+    for (int i = threadIdx.x; i < 3 * FC; i += 768) w3s[i] = S.w3[i];
     __syncthreads();
     const int total = pre[TF_N_SHARDS];
     const long long n_tiles = (total + 15) / 16;
     const int v_begin = (int)(((long long)blockIdx.x * n_tiles) / (long long)gridDim.x) * 16;
     const int v_end = min(total, (int)((((long long)blockIdx.x + 1) * n_tiles) / (long long)gridDim.x) * 16);
     // (a chunk is cut short where it would span a third shard — fwd_locate — so the chunk sequence is walked, not
-    // computed: both crews walk it alike, the MLP crew one chunk behind)
+    // computed.  The gather crew walks it, one chunk per iteration in its slack of P2 — a locate is ~2 k cycles of
+    // dependent LDS reads — and leaves the descriptors in a ring the MLP crew reads)
+    int4_desc* desc = reinterpret_cast<int4_desc*>(lds + L.offDesc);
     int tid0 = threadIdx.x;
     asm volatile("" : "+v"(tid0));
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -521,58 +548,60 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
     const int nb = (S.app_dim + 15) >> 4, ktb = kpad16(S.n_app_total) / 16;
     float* X = lds + L.offX;
     float* H1 = lds + L.offH1;
+    TF_ABL_INIT();
     TF_T0();
 
     if (wave < 8) {
         // ================= MLP crew =================
         const int f_base = 16 * wave, lane0 = tid0 & 63, lg0 = lane0 >> 4;
-        const bool basis_resident = KT1 <= 10 && nb <= 2 && ktb <= KTB;      // one (feature tile, sample tile) pair per wave
-        f32x4 fr1[KT1][1], fr2[FT][1], frb[KT1 <= 10 ? KTB : 1][1];
-        load_a_frags<1, KT1>(S.w1, kp1, f_base, kt1, lane0, fr1);
-        load_a_frags<1, FT>(S.w2, 16 * FT, f_base, FT, lane0, fr2);
-        if constexpr (KT1 <= 10) {
-            if (basis_resident && wave < 4 * nb) load_a_frags<1, KTB>(S.basis, 16 * ktb, 16 * (wave >> 2), ktb, lane0, frb);
-        }
+        f32x4 fr1[KT1][1], fr2[FT][1], frb[KTB][1];
+        load_resident_frags<KT1>(S.w1, kp1, f_base, kt1, lane0, fr1);
+        load_resident_frags<FT>(S.w2, FC, f_base, FT, lane0, fr2);
+        // basis: (feature tile, sample tile) pair `wave` (nb <= 2: at most 8 pairs); waves without a pair hold zeros
+        load_resident_frags<KTB>(S.basis, 16 * ktb, 16 * min(wave >> 2, nb - 1), wave < 4 * nb ? ktb : 0, lane0, frb);
         const f32x4 bias1 = *reinterpret_cast<const f32x4*>(S.b1 + f_base + 4 * lg0);
         const f32x4 bias2 = *reinterpret_cast<const f32x4*>(S.b2 + f_base + 4 * lg0);
-        FChunk ck;
+        const float b3 = S.b3[min(tid0 >> 6, 2)];      // P5: thread -> (channel tid / 64, sample tid % 64)
+        FChunk ck, ck_next;
         ck.s0 = ck.n0 = ck.s1 = ck.n1 = 0;
         bool on = false;
-        int v = v_begin;
-        for (int par = 0;; par ^= 1) {
+        bool more = fwd_locate(src, pre, v_begin, v_end, ck_next);      // chunk 0: the gather crew's chunk of iteration 0
+        TF_MARK(13);
+        for (int par = 0, it = 0;; par ^= 1, ++it) {
             // thread coordinates from an opaque copy of the thread id: no per-thread address is computed (and kept in
             // registers) outside the chunk loop — the crew has ~40 registers beside its weights
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));
             const int lane = tid & 63, lc = lane & 15, lg = lane >> 4;
-            FChunk ck_next;
-            const bool more = fwd_locate(src, pre, v, v_end, ck_next);      // the gather crew's chunk of this iteration
-            v += ck_next.n();
             const int n = on ? ck.n() : 0, nt = (n + 15) >> 4, n16 = 16 * nt;
-            const float* V = lds + (par ? L.offV0 : L.offV1);               // filled during the previous iteration
+            float* V = lds + (par ? L.offV0 : L.offV1);                     // filled during the previous iteration
             const float* ixyz = lds + (par ? L.offInfo0 : L.offInfo1);
             const float* iview = ixyz + 3 * M;
             auto at = [&](int r) { return ck.at(r); };
-            // ---- P1: feat = B V^T -> X, view columns
+            TF_MARK(10);
+            // ---- P1: feat = B V^T -> X (pair `wave`: all nine operand tiles read, then two accumulator chains), view
             if (on && !TF_ABL(16)) {
-                for (int pr = wave; pr < 4 * nb; pr += 8) {
-                    const int bf = pr >> 2, bs = pr & 3;
-                    if (bs >= nt) continue;
-                    f32x4 acc[1][1];
-                    acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    bool done = false;
-                    if constexpr (KT1 <= 10) {
-                        if (basis_resident) {
-                            mma_frags<1, 1, KTB>(frb, V, L.sv, 16 * bs, ktb, acc, lane);
-                            done = true;
+                const int bf = wave >> 2, bs = wave & 3;
+                if (wave < 4 * nb && bs < nt) {
+                    const float* vp = V + (16 * bs + lc) * L.sv + 4 * lg;
+                    f32x4 bv[KTB];
+#pragma unroll
+                    for (int kg = 0; kg < KTB; ++kg) bv[kg] = *reinterpret_cast<const f32x4*>(vp + 16 * kg);
+                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kg = 0; kg < KTB; ++kg)
+#pragma unroll
+                        for (int e = 0; e < 4; e += 2) {
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(frb[kg][0][e], bv[kg][e], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(frb[kg][0][e + 1], bv[kg][e + 1], acc1, 0, 0, 0);
                         }
-                    }
-                    if (!done) mma_block<1, 1>(S.basis, 16 * ktb, 16 * bf, V, L.sv, 16 * bs, ktb, acc, lane);
+                    const f32x4 acc = acc0 + acc1;
+                    TF_MARK(11);
                     const int row = 16 * bs + lc;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int f = 16 * bf + 4 * lg + e;
-                        if (f < S.app_dim) X[row * L.sx + f] = acc[0][0][e];
+                        if (f < S.app_dim) X[row * L.sx + f] = acc[e];
                     }
                 }
                 if (tid < M) {
@@ -602,14 +631,16 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
                     const float* mk = S.pe[b].mask;
                     const float* xb = X;
                     const int sx = L.sx;
-                    pe_block<NC>(X, L.sx, off, D, F, mk, tid, [&](int s_, int d) {
+                    pe_block<768>(X, L.sx, off, D, F, mk, tid, [&](int s_, int d) {      // (both crews: 768 threads)
                         return src_k == TF_SRC_FEAT ? xb[s_ * sx + d] : (src_k == TF_SRC_VIEW ? iview[s_ * 3 + d] : ixyz[s_ * 3 + d]);
                     }, n16);
                     off += 2 * D * F;
                 }
-                for (int i2 = tid; i2 < n16 * 16; i2 += NC) {     // the K padding is < 16 columns
-                    const int s_ = i2 >> 4, c = S.in_c + (i2 & 15);
-                    if (c < kp1) X[s_ * L.sx + c] = 0.f;
+                // zero K padding up to the template's extent
+                const int padw = 16 * KT1 - S.in_c;
+                for (int i2 = tid; i2 < n16 * padw; i2 += NC) {
+                    const int s_ = i2 / padw, c = S.in_c + (i2 - s_ * padw);
+                    X[s_ * L.sx + c] = 0.f;
                 }
             }
             TF_MARK(2);
@@ -622,8 +653,8 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (TF_ABL(8)) {}
-                else if (nt > 2) mma_frags<1, 4, KT1>(fr1, X, L.sx, 0, kt1, acc, lane);
-                else mma_frags<1, 2, KT1>(fr1, X, L.sx, 0, kt1, reinterpret_cast<f32x4 (&)[1][2]>(acc), lane);
+                else if (nt > 2) mma_frags<1, 4, KT1>(fr1, X, L.sx, 0, KT1, acc, lane);
+                else mma_frags<1, 2, KT1>(fr1, X, L.sx, 0, KT1, reinterpret_cast<f32x4 (&)[1][2]>(acc), lane);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (j >= nt) continue;
@@ -636,15 +667,20 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
             TF_MARK(4);
             lds_barrier();
             TF_MARK(5);
-            // ---- P4: H2 = relu(W2 H1 + b2), written over X
+            // ---- P4: H2 = relu(W2 H1 + b2), written over X; this wave's 16 features of the output layer's sums go to the
+            // (now free) V tile of this chunk as 32 partials per (channel, sample): part[4 wave + lg][c][s]
             if (on) {
-                if (save.h1) save_rows<NC>(save.h1, H1, L.sh, 16 * FT, n, tid, at);
+                if (save.h1) save_rows<NC>(save.h1, H1, L.sh, FC, n, tid, at);
                 f32x4 acc[1][4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (TF_ABL(8)) {}
                 else if (nt > 2) mma_frags<1, 4, FT>(fr2, H1, L.sh, 0, FT, acc, lane);
                 else mma_frags<1, 2, FT>(fr2, H1, L.sh, 0, FT, reinterpret_cast<f32x4 (&)[1][2]>(acc), lane);
+                f32x4 w3r[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) w3r[c] = *reinterpret_cast<const f32x4*>(w3s + c * FC + f_base + 4 * lg);
+                float* part = V + (4 * wave + lg) * (3 * M);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (j >= nt) continue;
@@ -652,113 +688,147 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
 #pragma unroll
                     for (int e = 0; e < 4; ++e) h[e] = fmaxf(h[e], 0.f);
                     *reinterpret_cast<f32x4*>(X + (16 * j + lc) * L.sh + f_base + 4 * lg) = h;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        part[c * M + 16 * j + lc] = fmaf(h[3], w3r[c][3], fmaf(h[2], w3r[c][2], fmaf(h[1], w3r[c][1], h[0] * w3r[c][0])));
                 }
             }
             TF_MARK(6);
             lds_barrier();
             TF_MARK(7);
-            // ---- P5: training rows (the gather crew runs the output layer)
-            if (on && save.h2) save_rows<NC>(save.h2, X, L.sh, 16 * FT, n, tid, at);
+            // ---- P5: rgb = sigmoid(sum of the partials (fixed order) + b3)   mlp.py:36-38, 66-67
+            if (on) {
+                if (save.h2) save_rows<NC>(save.h2, X, L.sh, FC, n, tid, at);
+                if (tid < 3 * M) {
+                    const int c = tid >> 6, s_ = tid & 63;
+                    if (s_ < n) {
+                        float a = 0.f;
+#pragma unroll 8
+                        for (int q = 0; q < 32; ++q) a += V[q * (3 * M) + c * M + s_];
+                        rgb_out[ck.at(s_) * 3 + c] = 1.f / (1.f + expf(-(a + b3)));
+                    }
+                }
+            }
             TF_MARK(8);
             lds_barrier();
             TF_MARK(9);
             if (!more) break;
             ck = ck_next;
             on = true;
+            ck_next = desc_chunk(desc[(it + 1) & 3]);      // chunk it + 1, located by the gather crew in this iteration's P2
+            more = ck_next.n() > 0;
         }
         TF_PIPE_FLUSH(0, tf_phase_cycles);
     } else {
-        // ================= gather crew: chunk of this iteration; output layer of the previous one =================
-        const int fw = wave - 8;
+        // ================= gather crew: appearance rows of the chunk one ahead of the MLP crew's =================
+        __builtin_amdgcn_s_setprio(3);      // its few VALU / LDS instructions go ahead of the MLP crew's MFMA streams
         const bool quads = pipe_gather_ok(S);
-        const float b3[3] = {S.b3[0], S.b3[1], S.b3[2]};
-        f32x4 fr3[FT];      // W3 as rows 0..2 of a 16-row operand tile (the other rows zero), for the whole launch
-        {
-            const int lc0 = tid0 & 15, lg0 = (tid0 & 63) >> 4, r3 = lc0 < 3 ? lc0 : 2;
+        // Per-sample info runs one more chunk ahead: during the iteration that gathers chunk f, the coordinates (every lane
+        // of a sample's 4), ray index and view direction (lane 0 of the 4) of chunk f + 1 are requested in P1 / P2 and
+        // written to the info tile in P4 — a whole phase between every request and its use.
+        float nx_x[3] = {0.f, 0.f, 0.f};
+        auto load_xyz = [&](const FChunk& c, bool have, int smp, int sub, float (&x)[3], int& ray) {
+            ray = -1;
 #pragma unroll
-            for (int k = 0; k < FT; ++k) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(S.w3 + r3 * (16 * FT) + 16 * k + 4 * lg0);
-                fr3[k] = lc0 < 3 ? w : (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-        }
-        // per-sample info, requested one iteration ahead: every lane of a sample's 4 holds its coordinates, lane 0 of the 4
-        // its ray index, then its view direction (app_ray -> rays: the second load goes out a phase after the first)
-        float nx_x[3] = {0.f, 0.f, 0.f}, nx_v[3] = {0.f, 0.f, 0.f};
-        int nx_ray = -1;
-        auto fetch_xyz = [&](const FChunk& c, int smp, int sub) {
-            nx_ray = -1;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) nx_x[a] = 0.f;
-            if (smp < c.n()) {
+            for (int a = 0; a < 3; ++a) x[a] = 0.f;
+            if (have && smp < c.n()) {
                 const size_t s = c.at(smp);
-                nx_x[0] = src.app_xyz[s * 3]; nx_x[1] = src.app_xyz[s * 3 + 1]; nx_x[2] = src.app_xyz[s * 3 + 2];
-                if (sub == 0 && src.rays) nx_ray = src.app_ray[s];
+                x[0] = src.app_xyz[s * 3]; x[1] = src.app_xyz[s * 3 + 1]; x[2] = src.app_xyz[s * 3 + 2];
+                if (sub == 0 && src.rays) ray = src.app_ray[s];
             }
         };
-        auto fetch_view = [&]() {
+        auto load_view = [&](int ray, float (&vd)[3]) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) nx_v[a] = 0.f;
-            if (nx_ray >= 0) {
-                const float* rp = src.rays + (size_t)nx_ray * 6 + 3;
-                nx_v[0] = rp[0]; nx_v[1] = rp[1]; nx_v[2] = rp[2];
+            for (int a = 0; a < 3; ++a) vd[a] = 0.f;
+            if (ray >= 0) {
+                const float* rp = src.rays + (size_t)ray * 6 + 3;
+                vd[0] = rp[0]; vd[1] = rp[1]; vd[2] = rp[2];
             }
         };
-        {
-            FChunk c0;
-            if (fwd_locate(src, pre, v_begin, v_end, c0)) fetch_xyz(c0, (tid0 - NC) >> 2, tid0 & 3);
-        }
-        FChunk ckm;
+        auto put_info = [&](float* ixyz, int smp, int n_valid, const float (&x)[3], float (&vd)[3]) {
+            if (src.ndc && smp < n_valid) {   // viewdirs / rays_norm  (tensorBase.py:341-343)
+                float q = vd[0] * vd[0];
+                q = q + vd[1] * vd[1];
+                q = q + vd[2] * vd[2];
+                const float nrm = sqrtf(q);
+                vd[0] = vd[0] / nrm; vd[1] = vd[1] / nrm; vd[2] = vd[2] / nrm;
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                ixyz[smp * 3 + a] = x[a];
+                ixyz[3 * M + smp * 3 + a] = vd[a];
+            }
+        };
+        FChunk ckf, ckm;
         ckm.s0 = ckm.n0 = ckm.s1 = ckm.n1 = 0;
-        bool on_m = false;
-        int v = v_begin;
-        for (int par = 0;; par ^= 1) {
+        bool on_f = fwd_locate(src, pre, v_begin, v_end, ckf), on_m = false;
+        int v = v_begin + ckf.n();
+        {      // chunk 0: requested and written here
+            const int smp = (tid0 - NC) >> 2, sub = tid0 & 3;
+            int ray;
+            float vd[3];
+            load_xyz(ckf, on_f, smp, sub, nx_x, ray);
+            load_view(ray, vd);
+            if (on_f && sub == 0) put_info(lds + L.offInfo0, smp, ckf.n(), nx_x, vd);
+        }
+        TF_MARK(13);
+        for (int par = 0, it = 0;; par ^= 1, ++it) {
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));
-            const int lane = tid & 63, lc = lane & 15, lg = lane >> 4;
             const int ftid = tid - NC, smp = ftid >> 2, sub = ftid & 3;      // gather: 4 lanes per sample
-            FChunk ckf;
-            const bool on_f = fwd_locate(src, pre, v, v_end, ckf);
-            v += ckf.n();
             const int nf = on_f ? ckf.n() : 0, n16f = 16 * ((nf + 15) >> 4);
-            const int nm = on_m ? ckm.n() : 0, ntm = (nm + 15) >> 4;
             float* V = lds + (par ? L.offV1 : L.offV0);
-            float* ixyz = lds + (par ? L.offInfo1 : L.offInfo0);
-            float* iview = ixyz + 3 * M;
+            float* info_next = lds + (par ? L.offInfo0 : L.offInfo1);        // (the MLP crew reads it in P1 / P2 only)
             float* vrow = V + smp * L.sv;
             const bool row_on = on_f && smp < n16f && !TF_ABL(4);
             const float u[3] = {nx_x[0], nx_x[1], nx_x[2]};
+            TF_MARK(10);
             VmTaps t;
             make_vm_taps(S.grid, u, t);
-            // ---- P1: unit 0; coordinates -> LDS; the view direction's request
-            fetch_view();
-            if (on_f && sub == 0) {
-#pragma unroll
-                for (int a = 0; a < 3; ++a) ixyz[smp * 3 + a] = nx_x[a];
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            TF_MARK(11);
+            // ---- P1: unit 0; the next chunk's coordinates and ray indices are requested
+            float nn_x[3], nn_v[3];
+            int nn_ray;
             if (row_on) {
                 if (quads) gather_units<0, 1>(S, t, sub, vrow);
-                for (int c = S.n_app_total + sub; c < kpad16(S.n_app_total); c += 4) vrow[c] = 0.f;
+                TF_MARK(12);
+                for (int c = S.n_app_total + sub; c < 16 * KTB; c += 4) vrow[c] = 0.f;
             }
             TF_MARK(0);
             lds_barrier();
             TF_MARK(1);
-            // ---- P2: units 1, 2; view direction -> LDS
-            if (on_f && sub == 0) {
-                if (src.ndc && smp < nf) {   // viewdirs / rays_norm  (tensorBase.py:341-343)
-                    float q = nx_v[0] * nx_v[0];
-                    q = q + nx_v[1] * nx_v[1];
-                    q = q + nx_v[2] * nx_v[2];
-                    const float nrm = sqrtf(q);
-                    nx_v[0] = nx_v[0] / nrm; nx_v[1] = nx_v[1] / nrm; nx_v[2] = nx_v[2] / nrm;
-                }
-#pragma unroll
-                for (int a = 0; a < 3; ++a) iview[smp * 3 + a] = nx_v[a];
-            }
+            // ---- P2: units 1, 2 requested; the next chunk located, its descriptor published, its coordinates and ray
+            // indices requested; this crew's third of the MLP crew's encodings
+            FChunk ckn;
+            const bool on_n = on_f && fwd_locate(src, pre, v, v_end, ckn);
+            if (!on_n) ckn.s0 = ckn.n0 = ckn.s1 = ckn.n1 = 0;
+            v += ckn.n();
+            if (ftid == 0) desc[(it + 1) & 3] = (int4_desc){ckn.s0, ckn.n0, ckn.s1, ckn.n1};
+            load_xyz(ckn, on_n, smp, sub, nn_x, nn_ray);
             if (row_on && quads) gather_units<1, 2>(S, t, sub, vrow);
+            if (on_m && !TF_ABL(16)) {
+                const int nm16 = 16 * ((ckm.n() + 15) >> 4);
+                float* X_ = lds + L.offX;
+                const float* ixyz_m = lds + (par ? L.offInfo0 : L.offInfo1);
+                const float* iview_m = ixyz_m + 3 * M;
+                int off = S.app_dim + 3;
+                for (int b = 0; b < S.n_pe; ++b) {
+                    const int src_k = S.pe[b].src, F = S.pe[b].freqs;
+                    const int D = src_k == TF_SRC_FEAT ? S.app_dim : 3;
+                    const float* mk = S.pe[b].mask;
+                    const int sx = L.sx;
+                    pe_block<768>(X_, L.sx, off, D, F, mk, tid, [&](int s_, int d) {
+                        return src_k == TF_SRC_FEAT ? X_[s_ * sx + d] : (src_k == TF_SRC_VIEW ? iview_m[s_ * 3 + d] : ixyz_m[s_ * 3 + d]);
+                    }, nm16);
+                    off += 2 * D * F;
+                }
+            }
             TF_MARK(2);
             lds_barrier();
             TF_MARK(3);
-            // ---- P3: units 3..5 (other field shapes: the whole row, tap by tap)
+            // ---- P3: units 3..5 (other field shapes: the whole row, tap by tap); the next chunk's view directions requested
+            load_view(nn_ray, nn_v);
             if (row_on) {
                 if (quads) gather_units<3, 3>(S, t, sub, vrow);
                 else app_products(S, u, sub, vrow, 4);
@@ -766,45 +836,23 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
             TF_MARK(4);
             lds_barrier();
             TF_MARK(5);
-            // ---- P4: units 6..8
+            // ---- P4: units 6..8; the next chunk's info -> LDS
             if (row_on && quads) gather_units<6, 3>(S, t, sub, vrow);
+            if (on_n && sub == 0) put_info(info_next, smp, ckn.n(), nn_x, nn_v);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) nx_x[a] = nn_x[a];
             TF_MARK(6);
             lds_barrier();
             TF_MARK(7);
-            // ---- P5: the next chunk's coordinates (requests only); output layer of the previous chunk (its H2 lies in X)
-            {
-                FChunk c1;
-                nx_ray = -1;
-                if (on_f && fwd_locate(src, pre, v, v_end, c1)) fetch_xyz(c1, smp, sub);
-                else { nx_x[0] = nx_x[1] = nx_x[2] = 0.f; }
-            }
-            if (fw < ntm) {     // o[c][s] = sum_f W3[c][f] H2[s][f]; W3 as rows 0..2 of a 16-row operand tile
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                const float* xp = X + (16 * fw + lc) * L.sh + 4 * lg;
-#pragma unroll
-                for (int k = 0; k < FT; ++k) {
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(xp + 16 * k);
-#pragma unroll
-                    for (int e = 0; e < 4; e += 2) {
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fr3[k][e], b[e], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fr3[k][e + 1], b[e + 1], acc1, 0, 0, 0);
-                    }
-                }
-                const f32x4 acc = acc0 + acc1;
-                const int row = 16 * fw + lc;      // D[c = 4 lg + reg][s = lc]: lanes 0..15 hold the three channels
-                if (lg == 0 && row < nm) {
-                    float* o = rgb_out + ckm.at(row) * 3;
-                    o[0] = 1.f / (1.f + expf(-(acc[0] + b3[0])));
-                    o[1] = 1.f / (1.f + expf(-(acc[1] + b3[1])));
-                    o[2] = 1.f / (1.f + expf(-(acc[2] + b3[2])));
-                }
-            }
+            // ---- P5: (the MLP crew finishes the output layer)
             TF_MARK(8);
             lds_barrier();
             TF_MARK(9);
             if (!on_f) break;
             ckm = ckf;
             on_m = true;
+            ckf = ckn;
+            on_f = on_n;
         }
         TF_PIPE_FLUSH(512, tf_phase_cycles_w4);
     }
@@ -852,17 +900,15 @@ int launch_shade(const TfShade* S, const TileSrc& src, float* rgb_out, float* fe
 int g_forward_variant = 0;
 
 bool pipe_fits(const TfShade& S) {
-    if (S.head != TF_HEAD_MLP || S.feature_c != 128 || kpad16(S.in_c) > 192) return false;
-    return (size_t)pipe_lds(S).total * sizeof(float) <= 160 * 1024 - 512;
+    return S.head == TF_HEAD_MLP && S.feature_c == 16 * PIPE_FT && S.in_c <= 16 * PIPE_KT1 && S.app_dim <= 32 &&
+           S.n_app_total <= 16 * PIPE_KTB;
 }
 
 int launch_shade_pipe(const TfShade* S, const TileSrc& src, float* rgb_out, int blocks, hipStream_t st, const TfShadeSave& save) {
-    typedef void (*pipe_fn_t)(const TfShade, const TileSrc, float*, const TfShadeSave);
-    pipe_fn_t fn = kpad16(S->in_c) <= 160 ? shade_forward_pipe_kernel<10> : shade_forward_pipe_kernel<12>;
-    const size_t bytes = (size_t)pipe_lds(*S).total * sizeof(float);
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(fn), bytes);
+    const size_t bytes = (size_t)pipe_lds().total * sizeof(float);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(shade_forward_pipe_kernel), bytes);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(fn, dim3(blocks), dim3(768), bytes, st, *S, src, rgb_out, save);
+    hipLaunchKernelGGL(shade_forward_pipe_kernel, dim3(blocks), dim3(768), bytes, st, *S, src, rgb_out, save);
     return TF_CHECK_LAUNCH();
 }
 
