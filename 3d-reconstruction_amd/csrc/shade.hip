@@ -402,49 +402,55 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
 // issue.  Here ONE 768-thread workgroup owns the CU and its 12 waves (three per SIMD: 168 VGPRs) are two crews working on
 // consecutive chunks, in lock step through five LDS-only barriers per iteration (s_barrier counts waves, whichever
 // instruction they arrive at):
-//   waves 0..7  (MLP crew),   chunk c:   P1 basis, view -> X   P2 encodings -> X   P3 X -> H1   P4 H1 -> H2, W3 partials
-//                                        P5 output layer's sum + sigmoid
-//   waves 8..11 (gather crew), chunk c + 1: the nine (plane, channel-quad) units of the appearance gather -> V', dealt
-//                             1 / 2 / 3 / 3 / 0 over the phases; coordinates and view directions of chunk c + 2
-// The MLP crew keeps its slice of W1, W2 and the basis (one 16-feature tile per wave, 108 VGPRs) and the biases in
-// registers for the whole launch and never waits for global memory; the gather — the only bulk fetch — runs beside
-// everything else instead of in front of it; nothing on either crew's path waits for a load it has just issued.  LDS: X
-// (H2 overlays it), H1, V and the sample info double-buffered, W3 — 157 KB.  The k extents are the template's (10 / 9 / 8
-// k-groups: in_c <= 160, n_app_total <= 144): shorter operands are zero padded, the MFMA loops carry no guards.  Shapes
-// beyond that (or other heads / hidden widths) use the kernel above.
-constexpr int PIPE_KT1 = 10, PIPE_KTB = 9, PIPE_FT = 8;
-struct PipeLds {
-    int sv, sx, sh;
-    int offX, offH1, offV0, offV1, offInfo0, offInfo1, offW3, offDesc, offPre, total;
+//   waves 0..7  (MLP crew),   chunk c:   P1 basis, view -> X   P2 encodings -> X   P3 X -> H1   P4 H1 -> H2   P5 output layer
+//   waves 8..11 (gather crew), chunk c + 1: the nine (plane, channel-quad) units of the appearance gather -> V, dealt
+//                             0 / 3 / 3 / 3 / 0 over the phases; coordinates and view directions of chunk c + 2
+// The MLP crew keeps its slice of W1 and W2 (one 16-feature tile per wave) in registers for the whole launch and never
+// waits for a load it has just issued; the gather — the only bulk fetch — runs beside everything else.
+//
+// The hidden layers and the output layer run on the bf16 matrix pipe at FULL fp32 accuracy: every operand is three
+// bf16 pieces, x = h + m + l, each the next 8 bits of the significand (truncation: exact), and a product is the six terms
+// hh + hm + mh + mm + hl + lh on v_mfma_f32_16x16x32_bf16 — 6 instructions of 4 passes per 32 k where the fp32 path
+// issues 8 of 8 passes (2.7 x); the dropped terms ml, lm, ll are <= 2^-24 of |a||b| each: max error 1.4e-7 of the largest
+// entry against 3.0e-7 for v_mfma_f32_16x16x4_f32 itself (profiles/r03_mfma_bf16x3_probe.txt).  The activations live in
+// LDS as three bf16 planes (6 B per element — the exact value, h + m + l reproduces the fp32 the training rows need), the
+// weights as three packed fragments per k-step in registers (108 VGPRs).  (On this hardware a wave that streams MFMAs
+// blocks the VALU of the other waves on its SIMD — same probe — so the matrix time is not hidden behind anything: it had to
+// shrink.)  The basis product (K = 144, 7 % of the flops) stays on the fp32 instruction.
+//
+// LDS: X planes (H2 overlays them), H1 planes, V, the sample info double-buffered, W3 planes, biases — 158 KB.  The k
+// extents are fixed (160 / 144 / 128: in_c <= 160, n_app_total <= 144): shorter operands are zero padded, the MFMA loops
+// carry no guards.  Shapes beyond that (or other heads / hidden widths) use the kernel above.
+constexpr int PIPE_KX = 160, PIPE_KB = 144, PIPE_FC = 128;
+constexpr int PIPE_XROW = 2 * PIPE_KX + 16, PIPE_HROW = 2 * PIPE_FC + 16;      // plane row strides in BYTES (conflict-free b128 reads)
+constexpr int PIPE_XPLANE = M * PIPE_XROW, PIPE_HPLANE = M * PIPE_HROW;
+struct PipeLds {      // byte offsets
+    int sv;           // V row stride in floats
+    int offX, offH1, offV, offInfo0, offInfo1, offW3, offBias, offDesc, offPre, total;
 };
 __host__ __device__ inline PipeLds pipe_lds() {
     PipeLds L;
-    L.sv = 16 * PIPE_KTB + 4;
-    L.sx = 16 * PIPE_KT1 + 4;
-    L.sh = 16 * PIPE_FT + 4;
+    L.sv = PIPE_KB + 4;
     L.offX = 0;
-    L.offH1 = M * L.sx;
-    L.offV0 = L.offH1 + M * L.sh;
-    L.offV1 = L.offV0 + M * L.sv;
-    L.offInfo0 = L.offV1 + M * L.sv;
-    L.offInfo1 = L.offInfo0 + M * 6;
-    L.offW3 = L.offInfo1 + M * 6;
-    L.offDesc = L.offW3 + 3 * 16 * PIPE_FT;      // ring of 4 chunk descriptors (FChunk), written by the gather crew
-    L.offPre = L.offDesc + 16;
-    L.total = L.offPre + 68;
+    L.offH1 = 3 * PIPE_XPLANE;
+    L.offV = L.offH1 + 3 * PIPE_HPLANE;
+    L.offInfo0 = L.offV + M * L.sv * 4;
+    L.offInfo1 = L.offInfo0 + M * 6 * 4;
+    L.offW3 = L.offInfo1 + M * 6 * 4;                 // three planes of [3][128] bf16
+    L.offBias = L.offW3 + 3 * 3 * PIPE_FC * 2;       // b1, b2
+    L.offDesc = L.offBias + 2 * PIPE_FC * 4;         // ring of 4 chunk descriptors (FChunk), written by the gather crew
+    L.offPre = L.offDesc + 64;
+    L.total = L.offPre + 68 * 4;
     return L;
 }
 
 #ifdef TF_PHASE_TIMING      // diagnostic build: 4 = no gather, 8 = no hidden-layer MFMAs, 16 = no basis / encodings (timing only)
 #define TF_ABL_INIT() const int abl_ = __builtin_amdgcn_readfirstlane(tf_dbg_flags)
 #define TF_ABL(bit) (abl_ & (bit))
+#define TF_PIPE_FLUSH(first_thread, arr) do { if ((int)threadIdx.x == (first_thread)) for (int _i = 0; _i < 16; ++_i) atomicAdd(&arr[_i], _ph[_i]); } while (0)
 #else
 #define TF_ABL_INIT()
 #define TF_ABL(bit) 0
-#endif
-#ifdef TF_PHASE_TIMING
-#define TF_PIPE_FLUSH(first_thread, arr) do { if ((int)threadIdx.x == (first_thread)) for (int _i = 0; _i < 16; ++_i) atomicAdd(&arr[_i], _ph[_i]); } while (0)
-#else
 #define TF_PIPE_FLUSH(first_thread, arr)
 #endif
 
@@ -496,8 +502,6 @@ __host__ __device__ inline bool pipe_gather_ok(const TfShade& S) {
         if ((S.app.n_comp[i] & 3) != 0 || S.app.n_comp[i] > 48) return false;
     return true;
 }
-// weight fragments of a wave's feature tile for the whole launch; k-groups past the matrix are ZERO (the operand tiles in
-// LDS are padded with zeros to the template's extent, so the products there are 0 x 0)
 typedef int int4_desc __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ FChunk desc_chunk(const int4_desc d) {      // wave-uniform copy (the fields index LDS / global rows)
     FChunk c;
@@ -507,6 +511,7 @@ __device__ __forceinline__ FChunk desc_chunk(const int4_desc d) {      // wave-u
     c.n1 = __builtin_amdgcn_readfirstlane(d[3]);
     return c;
 }
+// fp32 weight fragments of a wave's feature tile (the basis product); k-groups past the matrix are ZERO
 template <int KG>
 __device__ __forceinline__ void load_resident_frags(const float* __restrict__ Wg, int ldw, int f_base, int kgroups, int lane,
                                                     f32x4 (&a)[KG][1]) {
@@ -516,13 +521,138 @@ __device__ __forceinline__ void load_resident_frags(const float* __restrict__ Wg
         if (kg >= kgroups) a[kg][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
+// ---- three-piece bf16 operands -----------------------------------------------------------------------------------------
+// x = h + m + l exactly; every piece is returned in the UPPER half of a word (its lower half is zero)
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(h);                  // exact
+    m = __float_as_uint(r1) & 0xFFFF0000u;
+    l = __float_as_uint(r1 - __uint_as_float(m));             // exact, <= 8 significant bits
+}
+struct Frag3 {      // eight consecutive k of one row, as the three A (or B) operands of the K = 32 instruction
+    bf16x8 h, m, l;
+};
+__device__ __forceinline__ Frag3 split_frag(const float (&x)[8]) {
+    u32x4 ph, pm, pl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        split3(x[2 * i], h0, m0, l0);
+        split3(x[2 * i + 1], h1, m1, l1);
+        ph[i] = (h0 >> 16) | h1;
+        pm[i] = (m0 >> 16) | m1;
+        pl[i] = (l0 >> 16) | l1;
+    }
+    Frag3 f;
+    f.h = __builtin_bit_cast(bf16x8, ph);
+    f.m = __builtin_bit_cast(bf16x8, pm);
+    f.l = __builtin_bit_cast(bf16x8, pl);
+    return f;
+}
+// weight fragments of feature row f_base + (lane & 15) for KS k-steps of 32: W is row-major fp32 [.][ldw], zero beyond `cols`
+template <int KS>
+__device__ __forceinline__ void load_weight_frags3(const float* __restrict__ W, int ldw, int cols, int f_base, int lane, Frag3 (&a)[KS]) {
+    const int r = lane & 15, kq = lane >> 4;
+    const float* wp = W + (size_t)(f_base + r) * ldw + 8 * kq;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        float x[8];
+        const bool in = 32 * ks + 8 * kq < cols;       // (packed rows are padded to multiples of 16 with zeros: 8 k at a time are in or out)
+        const f32x4 lo = in ? *reinterpret_cast<const f32x4*>(wp + 32 * ks) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 hi = in ? *reinterpret_cast<const f32x4*>(wp + 32 * ks + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            x[e] = lo[e];
+            x[4 + e] = hi[e];
+        }
+        a[ks] = split_frag(x);
+    }
+}
+// one element into the three planes of a tile (plane stride `plane`, row stride `row`, both in bytes)
+__device__ __forceinline__ void put3(char* base, int plane, int row, int r, int c, float v) {
+    unsigned h, m, l;
+    split3(v, h, m, l);
+    char* p = base + r * row + 2 * c;
+    *reinterpret_cast<unsigned short*>(p) = (unsigned short)(h >> 16);
+    *reinterpret_cast<unsigned short*>(p + plane) = (unsigned short)(m >> 16);
+    *reinterpret_cast<unsigned short*>(p + 2 * plane) = (unsigned short)(l >> 16);
+}
+__device__ __forceinline__ float get3(const char* base, int plane, int row, int r, int c) {
+    const char* p = base + r * row + 2 * c;
+    const float h = __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(p) << 16);
+    const float m = __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(p + plane) << 16);
+    const float l = __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(p + 2 * plane) << 16);
+    return (h + m) + l;      // exact
+}
+// four consecutive features of one sample (an accumulator fragment) into the three planes: one 8-byte write per plane
+__device__ __forceinline__ void put3x4(char* base, int plane, int row, int r, int c, const f32x4& v) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split3(v[e], h[e], m[e], l[e]);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    char* p = base + r * row + 2 * c;
+    *reinterpret_cast<u32x2*>(p) = (u32x2){(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
+    *reinterpret_cast<u32x2*>(p + plane) = (u32x2){(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
+    *reinterpret_cast<u32x2*>(p + 2 * plane) = (u32x2){(l[0] >> 16) | l[1], (l[2] >> 16) | l[3]};
+}
+// training: the first n rows (w floats each, w a multiple of 4) of a plane tile back to fp32 rows in global memory
+template <int NT, typename AtFn>
+__device__ __forceinline__ void save_rows3(float* dst, const char* base, int plane, int row, int w, int n, int tid, AtFn at) {
+    const int w4 = w >> 2;
+    const float inv = 1.f / (float)w4;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    for (int q = tid; q < n * w4; q += NT) {
+        int r, c4;
+        row_quad(q, w4, inv, r, c4);
+        const char* p = base + r * row + 8 * c4;
+        const u32x2 h = *reinterpret_cast<const u32x2*>(p), m = *reinterpret_cast<const u32x2*>(p + plane),
+                    l = *reinterpret_cast<const u32x2*>(p + 2 * plane);
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            v[2 * i] = (__uint_as_float(h[i] << 16) + __uint_as_float(m[i] << 16)) + __uint_as_float(l[i] << 16);
+            v[2 * i + 1] = (__uint_as_float(h[i] & 0xFFFF0000u) + __uint_as_float(m[i] & 0xFFFF0000u)) + __uint_as_float(l[i] & 0xFFFF0000u);
+        }
+        *reinterpret_cast<f32x4*>(dst + at(r) * (size_t)w + 4 * c4) = v;
+    }
+}
+// acc[j] += W X^T for the wave's feature tile and sample tiles 0 .. NS-1 (NS = 2 or 4) over KS k-steps of 32: the six
+// products per (k-step, tile), smallest first, tiles of a pair alternating so that dependent MFMAs lie two apart
+template <int KS, int NS>
+__device__ __forceinline__ void mma3(const Frag3 (&a)[KS], const char* base, int plane, int row, f32x4 (&acc)[4], int lane) {
+    const char* bp = base + (lane & 15) * row + 16 * (lane >> 4);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int jp = 0; jp < NS / 2; ++jp) {
+            bf16x8 bh[2], bm[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const char* q = bp + (16 * (2 * jp + t)) * row + 64 * ks;
+                bh[t] = *reinterpret_cast<const bf16x8*>(q);
+                bm[t] = *reinterpret_cast<const bf16x8*>(q + plane);
+                bl[t] = *reinterpret_cast<const bf16x8*>(q + 2 * plane);
+            }
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const bf16x8 av = term == 0 ? a[ks].l : (term == 1 ? a[ks].h : (term == 2 ? a[ks].m : (term == 3 ? a[ks].m : a[ks].h)));
+                    const bf16x8 bv = term == 0 ? bh[t] : (term == 1 ? bl[t] : (term == 2 ? bm[t] : (term == 3 ? bh[t] : (term == 4 ? bm[t] : bh[t]))));
+                    acc[2 * jp + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[2 * jp + t], 0, 0, 0);
+                }
+        }
+}
+
 __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S, const TileSrc src, float* __restrict__ rgb_out,
                                                                  const TfShadeSave save) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NC = 512, KT1 = PIPE_KT1, KTB = PIPE_KTB, FT = PIPE_FT, FC = 16 * PIPE_FT;
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    constexpr int NC = 512, KTB = PIPE_KB / 16, FC = PIPE_FC, KS1 = PIPE_KX / 32, KS2 = PIPE_FC / 32;
+    constexpr int XR = PIPE_XROW, XP = PIPE_XPLANE, HR = PIPE_HROW, HP = PIPE_HPLANE;
     const PipeLds L = pipe_lds();
-    int* pre = reinterpret_cast<int*>(lds + L.offPre);
-    float* w3s = lds + L.offW3;                      // [3][128]
+    int* pre = reinterpret_cast<int*>(ldsb + L.offPre);
+    char* w3p = ldsb + L.offW3;                      // planes [3][3][128] bf16
+    float* biases = reinterpret_cast<float*>(ldsb + L.offBias);
     if (threadIdx.x == 0) {
         int run = 0;
         for (int g = 0; g < TF_N_SHARDS; ++g) {
@@ -531,37 +661,38 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
         }
         pre[TF_N_SHARDS] = run;
     }
-    for (int i = threadIdx.x; i < 3 * FC; i += 768) w3s[i] = S.w3[i];
+    for (int i = threadIdx.x; i < 3 * FC; i += 768) put3(w3p, 3 * FC * 2, FC * 2, i / FC, i % FC, S.w3[i]);
+    for (int i = threadIdx.x; i < 2 * FC; i += 768) biases[i] = i < FC ? S.b1[i] : S.b2[i - FC];
     __syncthreads();
     const int total = pre[TF_N_SHARDS];
     const long long n_tiles = (total + 15) / 16;
     const int v_begin = (int)(((long long)blockIdx.x * n_tiles) / (long long)gridDim.x) * 16;
     const int v_end = min(total, (int)((((long long)blockIdx.x + 1) * n_tiles) / (long long)gridDim.x) * 16);
     // (a chunk is cut short where it would span a third shard — fwd_locate — so the chunk sequence is walked, not
-    // computed.  The gather crew walks it, one chunk per iteration in its slack of P2 — a locate is ~2 k cycles of
-    // dependent LDS reads — and leaves the descriptors in a ring the MLP crew reads)
-    int4_desc* desc = reinterpret_cast<int4_desc*>(lds + L.offDesc);
+    // computed.  The gather crew walks it, one chunk per iteration in P2 — a locate is ~2 k cycles of dependent LDS reads —
+    // and leaves the descriptors in a ring the MLP crew reads)
+    int4_desc* desc = reinterpret_cast<int4_desc*>(ldsb + L.offDesc);
     int tid0 = threadIdx.x;
     asm volatile("" : "+v"(tid0));
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-    const int kp1 = kpad16(S.in_c), kt1 = kp1 / 16;
+    const int kp1 = kpad16(S.in_c);
     const int nb = (S.app_dim + 15) >> 4, ktb = kpad16(S.n_app_total) / 16;
-    float* X = lds + L.offX;
-    float* H1 = lds + L.offH1;
+    char* Xp = ldsb + L.offX;           // X planes (row stride XR); later the H2 planes (row stride HR, plane stride HP)
+    char* H1p = ldsb + L.offH1;
+    float* V = reinterpret_cast<float*>(ldsb + L.offV);
     TF_ABL_INIT();
     TF_T0();
 
     if (wave < 8) {
         // ================= MLP crew =================
-        const int f_base = 16 * wave, lane0 = tid0 & 63, lg0 = lane0 >> 4;
-        f32x4 fr1[KT1][1], fr2[FT][1], frb[KTB][1];
-        load_resident_frags<KT1>(S.w1, kp1, f_base, kt1, lane0, fr1);
-        load_resident_frags<FT>(S.w2, FC, f_base, FT, lane0, fr2);
-        // basis: (feature tile, sample tile) pair `wave` (nb <= 2: at most 8 pairs); waves without a pair hold zeros
+        const int f_base = 16 * wave, lane0 = tid0 & 63;
+        Frag3 a1[KS1], a2[KS2];
+        load_weight_frags3<KS1>(S.w1, kp1, kp1, f_base, lane0, a1);
+        load_weight_frags3<KS2>(S.w2, FC, FC, f_base, lane0, a2);
+        // basis (fp32): (feature tile, sample tile) pair `wave` (nb <= 2: at most 8 pairs); fetched one phase ahead of its
+        // use, every iteration (36 registers the hidden layers need)
+        f32x4 frb[KTB][1];
         load_resident_frags<KTB>(S.basis, 16 * ktb, 16 * min(wave >> 2, nb - 1), wave < 4 * nb ? ktb : 0, lane0, frb);
-        const f32x4 bias1 = *reinterpret_cast<const f32x4*>(S.b1 + f_base + 4 * lg0);
-        const f32x4 bias2 = *reinterpret_cast<const f32x4*>(S.b2 + f_base + 4 * lg0);
-        const float b3 = S.b3[min(tid0 >> 6, 2)];      // P5: thread -> (channel tid / 64, sample tid % 64)
         FChunk ck, ck_next;
         ck.s0 = ck.n0 = ck.s1 = ck.n1 = 0;
         bool on = false;
@@ -574,141 +705,147 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
             asm volatile("" : "+v"(tid));
             const int lane = tid & 63, lc = lane & 15, lg = lane >> 4;
             const int n = on ? ck.n() : 0, nt = (n + 15) >> 4, n16 = 16 * nt;
-            float* V = lds + (par ? L.offV0 : L.offV1);                     // filled during the previous iteration
-            const float* ixyz = lds + (par ? L.offInfo0 : L.offInfo1);
+            const float* ixyz = reinterpret_cast<const float*>(ldsb + (par ? L.offInfo0 : L.offInfo1));
             const float* iview = ixyz + 3 * M;
             auto at = [&](int r) { return ck.at(r); };
+            load_resident_frags<KTB>(S.basis, 16 * ktb, 16 * min(wave >> 2, nb - 1), wave < 4 * nb ? ktb : 0, lane, frb);
             TF_MARK(10);
             // ---- P1: feat = B V^T -> X (pair `wave`: all nine operand tiles read, then two accumulator chains), view
             if (on && !TF_ABL(16)) {
                 const int bf = wave >> 2, bs = wave & 3;
                 if (wave < 4 * nb && bs < nt) {
                     const float* vp = V + (16 * bs + lc) * L.sv + 4 * lg;
-                    f32x4 bv[KTB];
+                    // (operand tiles two k-groups ahead: with the layers' weights in registers there is room for no more)
+                    f32x4 bv[2];
 #pragma unroll
-                    for (int kg = 0; kg < KTB; ++kg) bv[kg] = *reinterpret_cast<const f32x4*>(vp + 16 * kg);
+                    for (int kg = 0; kg < 2; ++kg) bv[kg] = *reinterpret_cast<const f32x4*>(vp + 16 * kg);
                     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int kg = 0; kg < KTB; ++kg)
+                    for (int kg = 0; kg < KTB; ++kg) {
+                        const f32x4 b = bv[kg & 1];
+                        if (kg + 2 < KTB) bv[kg & 1] = *reinterpret_cast<const f32x4*>(vp + 16 * (kg + 2));
 #pragma unroll
                         for (int e = 0; e < 4; e += 2) {
-                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(frb[kg][0][e], bv[kg][e], acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(frb[kg][0][e + 1], bv[kg][e + 1], acc1, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(frb[kg][0][e], b[e], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(frb[kg][0][e + 1], b[e + 1], acc1, 0, 0, 0);
                         }
+                    }
                     const f32x4 acc = acc0 + acc1;
                     TF_MARK(11);
                     const int row = 16 * bs + lc;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int f = 16 * bf + 4 * lg + e;
-                        if (f < S.app_dim) X[row * L.sx + f] = acc[e];
+                        if (f < S.app_dim) put3(Xp, XP, XR, row, f, acc[e]);
                     }
                 }
-                if (tid < M) {
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) X[tid * L.sx + S.app_dim + a] = iview[tid * 3 + a];
-                }
+                if (tid < 3 * M) put3(Xp, XP, XR, tid / 3, S.app_dim + tid % 3, iview[tid]);
             }
             TF_MARK(0);
             lds_barrier();
             TF_MARK(1);
-            // ---- P2: positional-encoding blocks + zero K padding  (training rows leave phase by phase, each behind the
-            // barrier that completes it, so that the stores drain under the next phase's arithmetic)
+            // ---- P2: positional-encoding blocks + zero K padding
             if (on) {
-                if (save.v) {
-                    const int nat = S.n_app_total;
-                    if ((nat & 3) == 0) {
-                        save_rows<NC>(save.v, V, L.sv, nat, n, tid, at);
-                    } else {
-                        for (int r = wave; r < n; r += 8)
-                            for (int c = lane; c < nat; c += 64) save.v[ck.at(r) * nat + c] = V[r * L.sv + c];
-                    }
-                }
                 int off = S.app_dim + 3;
                 for (int b = 0; b < (TF_ABL(16) ? 0 : S.n_pe); ++b) {
                     const int src_k = S.pe[b].src, F = S.pe[b].freqs;
                     const int D = src_k == TF_SRC_FEAT ? S.app_dim : 3;
                     const float* mk = S.pe[b].mask;
-                    const float* xb = X;
-                    const int sx = L.sx;
-                    pe_block<768>(X, L.sx, off, D, F, mk, tid, [&](int s_, int d) {      // (both crews: 768 threads)
-                        return src_k == TF_SRC_FEAT ? xb[s_ * sx + d] : (src_k == TF_SRC_VIEW ? iview[s_ * 3 + d] : ixyz[s_ * 3 + d]);
-                    }, n16);
+                    pe_block_put<NC>(off, D, F, mk, tid, [&](int s_, int d) {
+                        return src_k == TF_SRC_FEAT ? get3(Xp, XP, XR, s_, d) : (src_k == TF_SRC_VIEW ? iview[s_ * 3 + d] : ixyz[s_ * 3 + d]);
+                    }, [&](int s_, int col, float v) { put3(Xp, XP, XR, s_, col, v); }, n16);
                     off += 2 * D * F;
                 }
-                // zero K padding up to the template's extent
-                const int padw = 16 * KT1 - S.in_c;
+                // zero K padding up to the fixed extent
+                const int padw = PIPE_KX - S.in_c;
                 for (int i2 = tid; i2 < n16 * padw; i2 += NC) {
                     const int s_ = i2 / padw, c = S.in_c + (i2 - s_ * padw);
-                    X[s_ * L.sx + c] = 0.f;
+                    char* p = Xp + s_ * XR + 2 * c;
+                    *reinterpret_cast<unsigned short*>(p) = 0;
+                    *reinterpret_cast<unsigned short*>(p + XP) = 0;
+                    *reinterpret_cast<unsigned short*>(p + 2 * XP) = 0;
                 }
             }
             TF_MARK(2);
             lds_barrier();
             TF_MARK(3);
-            // ---- P3: H1 = relu(W1 X + b1)
+            // ---- P3: H1 = relu(W1 X + b1)   (training rows leave behind the barrier that completes them, so that the
+            // stores drain under the phase's arithmetic)
             if (on) {
-                if (save.x) save_rows<NC>(save.x, X, L.sx, kp1, n, tid, at);
-                f32x4 acc[1][4];
+                if (save.x) save_rows3<NC>(save.x, Xp, XP, XR, kp1, n, tid, at);
+                f32x4 acc[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (TF_ABL(8)) {}
-                else if (nt > 2) mma_frags<1, 4, KT1>(fr1, X, L.sx, 0, KT1, acc, lane);
-                else mma_frags<1, 2, KT1>(fr1, X, L.sx, 0, KT1, reinterpret_cast<f32x4 (&)[1][2]>(acc), lane);
+                else if (nt > 2) mma3<KS1, 4>(a1, Xp, XP, XR, acc, lane);
+                else mma3<KS1, 2>(a1, Xp, XP, XR, acc, lane);
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(biases + f_base + 4 * lg);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (j >= nt) continue;
-                    f32x4 h = acc[0][j] + bias1;
+                    f32x4 h = acc[j] + bias;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) h[e] = fmaxf(h[e], 0.f);
-                    *reinterpret_cast<f32x4*>(H1 + (16 * j + lc) * L.sh + f_base + 4 * lg) = h;
+                    put3x4(H1p, HP, HR, 16 * j + lc, f_base + 4 * lg, h);
+                    if (save.h1 && 16 * j + lc < n) *reinterpret_cast<f32x4*>(save.h1 + ck.at(16 * j + lc) * (size_t)FC + f_base + 4 * lg) = h;
                 }
             }
             TF_MARK(4);
             lds_barrier();
             TF_MARK(5);
-            // ---- P4: H2 = relu(W2 H1 + b2), written over X; this wave's 16 features of the output layer's sums go to the
-            // (now free) V tile of this chunk as 32 partials per (channel, sample): part[4 wave + lg][c][s]
+            // ---- P4: H2 = relu(W2 H1 + b2), written over X
             if (on) {
-                if (save.h1) save_rows<NC>(save.h1, H1, L.sh, FC, n, tid, at);
-                f32x4 acc[1][4];
+                f32x4 acc[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (TF_ABL(8)) {}
-                else if (nt > 2) mma_frags<1, 4, FT>(fr2, H1, L.sh, 0, FT, acc, lane);
-                else mma_frags<1, 2, FT>(fr2, H1, L.sh, 0, FT, reinterpret_cast<f32x4 (&)[1][2]>(acc), lane);
-                f32x4 w3r[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) w3r[c] = *reinterpret_cast<const f32x4*>(w3s + c * FC + f_base + 4 * lg);
-                float* part = V + (4 * wave + lg) * (3 * M);
+                else if (nt > 2) mma3<KS2, 4>(a2, H1p, HP, HR, acc, lane);
+                else mma3<KS2, 2>(a2, H1p, HP, HR, acc, lane);
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(biases + FC + f_base + 4 * lg);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (j >= nt) continue;
-                    f32x4 h = acc[0][j] + bias2;
+                    f32x4 h = acc[j] + bias;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) h[e] = fmaxf(h[e], 0.f);
-                    *reinterpret_cast<f32x4*>(X + (16 * j + lc) * L.sh + f_base + 4 * lg) = h;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        part[c * M + 16 * j + lc] = fmaf(h[3], w3r[c][3], fmaf(h[2], w3r[c][2], fmaf(h[1], w3r[c][1], h[0] * w3r[c][0])));
+                    put3x4(Xp, HP, HR, 16 * j + lc, f_base + 4 * lg, h);
+                    if (save.h2 && 16 * j + lc < n) *reinterpret_cast<f32x4*>(save.h2 + ck.at(16 * j + lc) * (size_t)FC + f_base + 4 * lg) = h;
                 }
             }
             TF_MARK(6);
             lds_barrier();
             TF_MARK(7);
-            // ---- P5: rgb = sigmoid(sum of the partials (fixed order) + b3)   mlp.py:36-38, 66-67
-            if (on) {
-                if (save.h2) save_rows<NC>(save.h2, X, L.sh, FC, n, tid, at);
-                if (tid < 3 * M) {
-                    const int c = tid >> 6, s_ = tid & 63;
-                    if (s_ < n) {
-                        float a = 0.f;
-#pragma unroll 8
-                        for (int q = 0; q < 32; ++q) a += V[q * (3 * M) + c * M + s_];
-                        rgb_out[ck.at(s_) * 3 + c] = 1.f / (1.f + expf(-(a + b3)));
-                    }
+            // ---- P5: output layer + sigmoid: o[c][s] = sum_f W3[c][f] H2[s][f], W3 as rows 0..2 of a 16-row operand tile
+            // (its planes in LDS); wave w < 4 takes sample tile w.   mlp.py:36-38, 66-67
+            if (on && wave < nt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+                const char* ap = w3p + min(lc, 2) * (FC * 2) + 16 * lg;
+                const char* bp = Xp + (16 * wave + lc) * HR + 16 * lg;
+#pragma unroll
+                for (int ks = 0; ks < KS2; ++ks) {
+                    bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap + 64 * ks), am = *reinterpret_cast<const bf16x8*>(ap + 3 * FC * 2 + 64 * ks),
+                           al = *reinterpret_cast<const bf16x8*>(ap + 2 * 3 * FC * 2 + 64 * ks);
+                    if (lc >= 3) ah = am = al = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp + 64 * ks), bm = *reinterpret_cast<const bf16x8*>(bp + HP + 64 * ks),
+                                 bl = *reinterpret_cast<const bf16x8*>(bp + 2 * HP + 64 * ks);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+                }
+                acc += acc2;
+                const int row = 16 * wave + lc;      // D[c = 4 lg + reg][s = lc]: lanes 0..15 hold the three channels
+                if (lg == 0 && row < n) {
+                    float* o = rgb_out + ck.at(row) * 3;
+                    o[0] = 1.f / (1.f + expf(-(acc[0] + S.b3[0])));
+                    o[1] = 1.f / (1.f + expf(-(acc[1] + S.b3[1])));
+                    o[2] = 1.f / (1.f + expf(-(acc[2] + S.b3[2])));
                 }
             }
+            // the basis fragments of the next iteration's P1 (requested a phase ahead)
+
             TF_MARK(8);
             lds_barrier();
             TF_MARK(9);
@@ -721,10 +858,10 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
         TF_PIPE_FLUSH(0, tf_phase_cycles);
     } else {
         // ================= gather crew: appearance rows of the chunk one ahead of the MLP crew's =================
-        __builtin_amdgcn_s_setprio(3);      // its few VALU / LDS instructions go ahead of the MLP crew's MFMA streams
+        __builtin_amdgcn_s_setprio(3);      // its few VALU / LDS instructions go ahead of the MLP crew's streams
         const bool quads = pipe_gather_ok(S);
         // Per-sample info runs one more chunk ahead: during the iteration that gathers chunk f, the coordinates (every lane
-        // of a sample's 4), ray index and view direction (lane 0 of the 4) of chunk f + 1 are requested in P1 / P2 and
+        // of a sample's 4), ray index and view direction (lane 0 of the 4) of chunk f + 1 are requested in P2 / P3 and
         // written to the info tile in P4 — a whole phase between every request and its use.
         float nx_x[3] = {0.f, 0.f, 0.f};
         auto load_xyz = [&](const FChunk& c, bool have, int smp, int sub, float (&x)[3], int& ray) {
@@ -769,7 +906,7 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
             float vd[3];
             load_xyz(ckf, on_f, smp, sub, nx_x, ray);
             load_view(ray, vd);
-            if (on_f && sub == 0) put_info(lds + L.offInfo0, smp, ckf.n(), nx_x, vd);
+            if (on_f && sub == 0) put_info(reinterpret_cast<float*>(ldsb + L.offInfo0), smp, ckf.n(), nx_x, vd);
         }
         TF_MARK(13);
         for (int par = 0, it = 0;; par ^= 1, ++it) {
@@ -777,8 +914,7 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
             asm volatile("" : "+v"(tid));
             const int ftid = tid - NC, smp = ftid >> 2, sub = ftid & 3;      // gather: 4 lanes per sample
             const int nf = on_f ? ckf.n() : 0, n16f = 16 * ((nf + 15) >> 4);
-            float* V = lds + (par ? L.offV1 : L.offV0);
-            float* info_next = lds + (par ? L.offInfo0 : L.offInfo1);        // (the MLP crew reads it in P1 / P2 only)
+            float* info_next = reinterpret_cast<float*>(ldsb + (par ? L.offInfo0 : L.offInfo1));   // (the MLP crew reads it in P1 / P2 only)
             float* vrow = V + smp * L.sv;
             const bool row_on = on_f && smp < n16f && !TF_ABL(4);
             const float u[3] = {nx_x[0], nx_x[1], nx_x[2]};
@@ -787,42 +923,33 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
             make_vm_taps(S.grid, u, t);
             __builtin_amdgcn_sched_barrier(0);
             TF_MARK(11);
-            // ---- P1: unit 0; the next chunk's coordinates and ray indices are requested
+            // ---- P1: the MLP crew's basis product reads the one V tile: its rows leave for the backward (training), nothing
+            // is written
             float nn_x[3], nn_v[3];
             int nn_ray;
-            if (row_on) {
-                if (quads) gather_units<0, 1>(S, t, sub, vrow);
-                TF_MARK(12);
-                for (int c = S.n_app_total + sub; c < 16 * KTB; c += 4) vrow[c] = 0.f;
+            if (on_m && save.v) {
+                const int nat = S.n_app_total;
+                auto atm = [&](int r) { return ckm.at(r); };
+                if ((nat & 3) == 0) {
+                    save_rows<256>(save.v, V, L.sv, nat, ckm.n(), ftid, atm);
+                } else {
+                    for (int r = ftid >> 6; r < ckm.n(); r += 4)
+                        for (int c = ftid & 63; c < nat; c += 64) save.v[ckm.at(r) * nat + c] = V[r * L.sv + c];
+                }
             }
             TF_MARK(0);
             lds_barrier();
             TF_MARK(1);
-            // ---- P2: units 1, 2 requested; the next chunk located, its descriptor published, its coordinates and ray
-            // indices requested; this crew's third of the MLP crew's encodings
+            // ---- P2: units 0..2; the next chunk located, its descriptor published, its coordinates and ray indices requested
             FChunk ckn;
             const bool on_n = on_f && fwd_locate(src, pre, v, v_end, ckn);
             if (!on_n) ckn.s0 = ckn.n0 = ckn.s1 = ckn.n1 = 0;
             v += ckn.n();
             if (ftid == 0) desc[(it + 1) & 3] = (int4_desc){ckn.s0, ckn.n0, ckn.s1, ckn.n1};
             load_xyz(ckn, on_n, smp, sub, nn_x, nn_ray);
-            if (row_on && quads) gather_units<1, 2>(S, t, sub, vrow);
-            if (on_m && !TF_ABL(16)) {
-                const int nm16 = 16 * ((ckm.n() + 15) >> 4);
-                float* X_ = lds + L.offX;
-                const float* ixyz_m = lds + (par ? L.offInfo0 : L.offInfo1);
-                const float* iview_m = ixyz_m + 3 * M;
-                int off = S.app_dim + 3;
-                for (int b = 0; b < S.n_pe; ++b) {
-                    const int src_k = S.pe[b].src, F = S.pe[b].freqs;
-                    const int D = src_k == TF_SRC_FEAT ? S.app_dim : 3;
-                    const float* mk = S.pe[b].mask;
-                    const int sx = L.sx;
-                    pe_block<768>(X_, L.sx, off, D, F, mk, tid, [&](int s_, int d) {
-                        return src_k == TF_SRC_FEAT ? X_[s_ * sx + d] : (src_k == TF_SRC_VIEW ? iview_m[s_ * 3 + d] : ixyz_m[s_ * 3 + d]);
-                    }, nm16);
-                    off += 2 * D * F;
-                }
+            if (row_on) {
+                if (quads) gather_units<0, 3>(S, t, sub, vrow);
+                for (int c = S.n_app_total + sub; c < PIPE_KB; c += 4) vrow[c] = 0.f;
             }
             TF_MARK(2);
             lds_barrier();
@@ -844,7 +971,7 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
             TF_MARK(6);
             lds_barrier();
             TF_MARK(7);
-            // ---- P5: (the MLP crew finishes the output layer)
+            // ---- P5: (the MLP crew runs the output layer)
             TF_MARK(8);
             lds_barrier();
             TF_MARK(9);
@@ -900,12 +1027,11 @@ int launch_shade(const TfShade* S, const TileSrc& src, float* rgb_out, float* fe
 int g_forward_variant = 0;
 
 bool pipe_fits(const TfShade& S) {
-    return S.head == TF_HEAD_MLP && S.feature_c == 16 * PIPE_FT && S.in_c <= 16 * PIPE_KT1 && S.app_dim <= 32 &&
-           S.n_app_total <= 16 * PIPE_KTB;
+    return S.head == TF_HEAD_MLP && S.feature_c == PIPE_FC && S.in_c <= PIPE_KX && S.app_dim <= 32 && S.n_app_total <= PIPE_KB;
 }
 
 int launch_shade_pipe(const TfShade* S, const TileSrc& src, float* rgb_out, int blocks, hipStream_t st, const TfShadeSave& save) {
-    const size_t bytes = (size_t)pipe_lds().total * sizeof(float);
+    const size_t bytes = (size_t)pipe_lds().total;
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(shade_forward_pipe_kernel), bytes);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(shade_forward_pipe_kernel, dim3(blocks), dim3(768), bytes, st, *S, src, rgb_out, save);

@@ -376,15 +376,13 @@ __device__ __forceinline__ bool app_products_lanes4(const TfShade& S, const floa
 // frequencies v*2^k -> sin at x[off + d*F + k], cos at x[off + D*F + d*F + k], times the optional masks.
 // `val(smp, d)` supplies v.  NT threads cooperate.  The F evaluations of an item are independent and evaluated
 // branch-free two at a time unless some lane of the wave holds a huge argument (wave-uniform test).
-template <int NT, typename ValFn>
-__device__ __forceinline__ void pe_block(float* X, int sx, int off, int D, int F, const float* mk, int tid, ValFn val,
-                                         int rows = M) {
+template <int NT, typename ValFn, typename PutFn>
+__device__ __forceinline__ void pe_block_put(int off, int D, int F, const float* mk, int tid, ValFn val, PutFn put, int rows = M) {
     // thread -> (sample, dim) without integer division: dims padded to a power of two
     const int dp = D <= 4 ? 4 : (D <= 32 ? 32 : 64), dsh = D <= 4 ? 2 : (D <= 32 ? 5 : 6);
     for (int it = tid; it < rows * dp; it += NT) {
         const int smp = it >> dsh, d = it & (dp - 1);
         const bool on = d < D;
-        float* x = X + smp * sx;
         const float v = on ? val(smp, d) : 0.f;
         const float vmax = ldexpf(fabsf(v), F - 1);
         if (__builtin_expect(__any(!(vmax < 8192.f)), 0)) {        // rare: some lane needs the full range reduction
@@ -398,8 +396,8 @@ __device__ __forceinline__ void pe_block(float* X, int sx, int off, int D, int F
                         sn *= mk[ci];
                         cs *= mk[D * F + ci];
                     }
-                    x[off + ci] = sn;
-                    x[off + D * F + ci] = cs;
+                    put(smp, off + ci, sn);
+                    put(smp, off + D * F + ci, cs);
                     fr *= 2.f;
                 }
             }
@@ -422,10 +420,10 @@ __device__ __forceinline__ void pe_block(float* X, int sx, int off, int D, int F
                 c1 *= mk[D * F + ci + 1];
             }
             if (on) {
-                x[off + ci] = s0;
-                x[off + ci + 1] = s1;
-                x[off + D * F + ci] = c0;
-                x[off + D * F + ci + 1] = c1;
+                put(smp, off + ci, s0);
+                put(smp, off + ci + 1, s1);
+                put(smp, off + D * F + ci, c0);
+                put(smp, off + D * F + ci + 1, c1);
             }
             fr *= 4.f;
         }
@@ -438,11 +436,17 @@ __device__ __forceinline__ void pe_block(float* X, int sx, int off, int D, int F
                 c0 *= mk[D * F + ci];
             }
             if (on) {
-                x[off + ci] = s0;
-                x[off + D * F + ci] = c0;
+                put(smp, off + ci, s0);
+                put(smp, off + D * F + ci, c0);
             }
         }
     }
+}
+// ... into a row-major fp32 tile X (row stride sx)
+template <int NT, typename ValFn>
+__device__ __forceinline__ void pe_block(float* X, int sx, int off, int D, int F, const float* mk, int tid, ValFn val,
+                                         int rows = M) {
+    pe_block_put<NT>(off, D, F, mk, tid, val, [&](int smp, int col, float v) { X[smp * sx + col] = v; }, rows);
 }
 
 // row / quad of item q of a [64][w4] quad image without an integer division (q < 4096, w4 <= 96: exact)
