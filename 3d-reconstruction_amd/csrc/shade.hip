@@ -437,8 +437,8 @@ __host__ __device__ inline PipeLds pipe_lds() {
     L.offInfo0 = L.offV + M * L.sv * 4;
     L.offInfo1 = L.offInfo0 + M * 6 * 4;
     L.offW3 = L.offInfo1 + M * 6 * 4;                 // three planes of [3][128] bf16
-    L.offBias = L.offW3 + 3 * 3 * PIPE_FC * 2;       // b1, b2
-    L.offDesc = L.offBias + 2 * PIPE_FC * 4;         // ring of 4 chunk descriptors (FChunk), written by the gather crew
+    L.offBias = L.offW3 + 3 * 3 * PIPE_FC * 2;       // b1, b2, b3
+    L.offDesc = L.offBias + (2 * PIPE_FC + 4) * 4;   // ring of 4 chunk descriptors (FChunk), written by the gather crew
     L.offPre = L.offDesc + 64;
     L.total = L.offPre + 68 * 4;
     return L;
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
         pre[TF_N_SHARDS] = run;
     }
     for (int i = threadIdx.x; i < 3 * FC; i += 768) put3(w3p, 3 * FC * 2, FC * 2, i / FC, i % FC, S.w3[i]);
-    for (int i = threadIdx.x; i < 2 * FC; i += 768) biases[i] = i < FC ? S.b1[i] : S.b2[i - FC];
+    for (int i = threadIdx.x; i < 2 * FC + 3; i += 768) biases[i] = i < FC ? S.b1[i] : (i < 2 * FC ? S.b2[i - FC] : S.b3[i - 2 * FC]);
     __syncthreads();
     const int total = pre[TF_N_SHARDS];
     const long long n_tiles = (total + 15) / 16;
@@ -692,7 +692,6 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
         // basis (fp32): (feature tile, sample tile) pair `wave` (nb <= 2: at most 8 pairs); fetched one phase ahead of its
         // use, every iteration (36 registers the hidden layers need)
         f32x4 frb[KTB][1];
-        load_resident_frags<KTB>(S.basis, 16 * ktb, 16 * min(wave >> 2, nb - 1), wave < 4 * nb ? ktb : 0, lane0, frb);
         FChunk ck, ck_next;
         ck.s0 = ck.n0 = ck.s1 = ck.n1 = 0;
         bool on = false;
@@ -839,13 +838,11 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
                 const int row = 16 * wave + lc;      // D[c = 4 lg + reg][s = lc]: lanes 0..15 hold the three channels
                 if (lg == 0 && row < n) {
                     float* o = rgb_out + ck.at(row) * 3;
-                    o[0] = 1.f / (1.f + expf(-(acc[0] + S.b3[0])));
-                    o[1] = 1.f / (1.f + expf(-(acc[1] + S.b3[1])));
-                    o[2] = 1.f / (1.f + expf(-(acc[2] + S.b3[2])));
+                    o[0] = 1.f / (1.f + expf(-(acc[0] + biases[2 * FC])));
+                    o[1] = 1.f / (1.f + expf(-(acc[1] + biases[2 * FC + 1])));
+                    o[2] = 1.f / (1.f + expf(-(acc[2] + biases[2 * FC + 2])));
                 }
             }
-            // the basis fragments of the next iteration's P1 (requested a phase ahead)
-
             TF_MARK(8);
             lds_barrier();
             TF_MARK(9);
@@ -896,7 +893,7 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
                 ixyz[3 * M + smp * 3 + a] = vd[a];
             }
         };
-        FChunk ckf, ckm;
+        FChunk ckf, ckm, ckn;
         ckm.s0 = ckm.n0 = ckm.s1 = ckm.n1 = 0;
         bool on_f = fwd_locate(src, pre, v_begin, v_end, ckf), on_m = false;
         int v = v_begin + ckf.n();
@@ -908,6 +905,12 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
             load_view(ray, vd);
             if (on_f && sub == 0) put_info(reinterpret_cast<float*>(ldsb + L.offInfo0), smp, ckf.n(), nx_x, vd);
         }
+        // chunk 1: located here, then one chunk per iteration in P5, where this crew is idle (a locate is ~2 k cycles of
+        // dependent LDS reads)
+        bool on_n = on_f && fwd_locate(src, pre, v, v_end, ckn);
+        if (!on_n) ckn.s0 = ckn.n0 = ckn.s1 = ckn.n1 = 0;
+        v += ckn.n();
+        if (tid0 == NC) desc[1] = (int4_desc){ckn.s0, ckn.n0, ckn.s1, ckn.n1};
         TF_MARK(13);
         for (int par = 0, it = 0;; par ^= 1, ++it) {
             int tid = threadIdx.x;
@@ -940,12 +943,7 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
             TF_MARK(0);
             lds_barrier();
             TF_MARK(1);
-            // ---- P2: units 0..2; the next chunk located, its descriptor published, its coordinates and ray indices requested
-            FChunk ckn;
-            const bool on_n = on_f && fwd_locate(src, pre, v, v_end, ckn);
-            if (!on_n) ckn.s0 = ckn.n0 = ckn.s1 = ckn.n1 = 0;
-            v += ckn.n();
-            if (ftid == 0) desc[(it + 1) & 3] = (int4_desc){ckn.s0, ckn.n0, ckn.s1, ckn.n1};
+            // ---- P2: units 0..2; the next chunk's coordinates and ray indices requested
             load_xyz(ckn, on_n, smp, sub, nn_x, nn_ray);
             if (row_on) {
                 if (quads) gather_units<0, 3>(S, t, sub, vrow);
@@ -971,15 +969,19 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
             TF_MARK(6);
             lds_barrier();
             TF_MARK(7);
-            // ---- P5: (the MLP crew runs the output layer)
+            // ---- P5: (the MLP crew runs the output layer) the chunk after the next located, its descriptor published
+            ckm = ckf;
+            on_m = on_f;
+            ckf = ckn;
+            on_f = on_n;
+            on_n = on_f && fwd_locate(src, pre, v, v_end, ckn);
+            if (!on_n) ckn.s0 = ckn.n0 = ckn.s1 = ckn.n1 = 0;
+            v += ckn.n();
+            if (ftid == 0) desc[(it + 2) & 3] = (int4_desc){ckn.s0, ckn.n0, ckn.s1, ckn.n1};
             TF_MARK(8);
             lds_barrier();
             TF_MARK(9);
-            if (!on_f) break;
-            ckm = ckf;
-            on_m = true;
-            ckf = ckn;
-            on_f = on_n;
+            if (!on_m) break;
         }
         TF_PIPE_FLUSH(512, tf_phase_cycles_w4);
     }
