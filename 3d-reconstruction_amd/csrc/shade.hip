@@ -691,7 +691,6 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
         load_weight_frags3<KS2>(S.w2, FC, FC, f_base, lane0, a2);
         // basis (fp32): (feature tile, sample tile) pair `wave` (nb <= 2: at most 8 pairs); fetched one phase ahead of its
         // use, every iteration (36 registers the hidden layers need)
-        f32x4 frb[KTB][1];
         FChunk ck, ck_next;
         ck.s0 = ck.n0 = ck.s1 = ck.n1 = 0;
         bool on = false;
@@ -707,38 +706,25 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
             const float* ixyz = reinterpret_cast<const float*>(ldsb + (par ? L.offInfo0 : L.offInfo1));
             const float* iview = ixyz + 3 * M;
             auto at = [&](int r) { return ck.at(r); };
-            load_resident_frags<KTB>(S.basis, 16 * ktb, 16 * min(wave >> 2, nb - 1), wave < 4 * nb ? ktb : 0, lane, frb);
             TF_MARK(10);
-            // ---- P1: feat = B V^T -> X (pair `wave`: all nine operand tiles read, then two accumulator chains), view
+            // ---- P1: the appearance features and view directions of this chunk — computed by the gather crew during the
+            // previous iteration's P5 into a side tile (planes of [64][32] in the idle H1 region) — move into the X planes;
+            // training: the V rows leave for the backward (the gather crew overwrites the tile from P2 on)
             if (on && !TF_ABL(16)) {
-                const int bf = wave >> 2, bs = wave & 3;
-                if (wave < 4 * nb && bs < nt) {
-                    const float* vp = V + (16 * bs + lc) * L.sv + 4 * lg;
-                    // (operand tiles two k-groups ahead: with the layers' weights in registers there is room for no more)
-                    f32x4 bv[2];
-#pragma unroll
-                    for (int kg = 0; kg < 2; ++kg) bv[kg] = *reinterpret_cast<const f32x4*>(vp + 16 * kg);
-                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int kg = 0; kg < KTB; ++kg) {
-                        const f32x4 b = bv[kg & 1];
-                        if (kg + 2 < KTB) bv[kg & 1] = *reinterpret_cast<const f32x4*>(vp + 16 * (kg + 2));
-#pragma unroll
-                        for (int e = 0; e < 4; e += 2) {
-                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(frb[kg][0][e], b[e], acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(frb[kg][0][e + 1], b[e + 1], acc1, 0, 0, 0);
-                        }
-                    }
-                    const f32x4 acc = acc0 + acc1;
-                    TF_MARK(11);
-                    const int row = 16 * bs + lc;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int f = 16 * bf + 4 * lg + e;
-                        if (f < S.app_dim) put3(Xp, XP, XR, row, f, acc[e]);
+                for (int q = tid; q < 3 * n16 * 4; q += NC) {
+                    const int pl = q / (n16 * 4), rc = q - pl * (n16 * 4);
+                    *reinterpret_cast<u32x4*>(Xp + pl * XP + (rc >> 2) * XR + 16 * (rc & 3)) =
+                        *reinterpret_cast<const u32x4*>(H1p + pl * (M * 64) + (rc >> 2) * 64 + 16 * (rc & 3));
+                }
+                if (save.v) {
+                    const int nat = S.n_app_total;
+                    if ((nat & 3) == 0) {
+                        save_rows<NC>(save.v, V, L.sv, nat, n, tid, at);
+                    } else {
+                        for (int r = wave; r < n; r += 8)
+                            for (int c = lane; c < nat; c += 64) save.v[ck.at(r) * nat + c] = V[r * L.sv + c];
                     }
                 }
-                if (tid < 3 * M) put3(Xp, XP, XR, tid / 3, S.app_dim + tid % 3, iview[tid]);
             }
             TF_MARK(0);
             lds_barrier();
@@ -911,6 +897,7 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
         if (!on_n) ckn.s0 = ckn.n0 = ckn.s1 = ckn.n1 = 0;
         v += ckn.n();
         if (tid0 == NC) desc[1] = (int4_desc){ckn.s0, ckn.n0, ckn.s1, ckn.n1};
+        const int fw = wave - 8;
         TF_MARK(13);
         for (int par = 0, it = 0;; par ^= 1, ++it) {
             int tid = threadIdx.x;
@@ -926,20 +913,9 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
             make_vm_taps(S.grid, u, t);
             __builtin_amdgcn_sched_barrier(0);
             TF_MARK(11);
-            // ---- P1: the MLP crew's basis product reads the one V tile: its rows leave for the backward (training), nothing
-            // is written
+            // ---- P1: (the MLP crew moves the feature tile and saves the V rows)
             float nn_x[3], nn_v[3];
             int nn_ray;
-            if (on_m && save.v) {
-                const int nat = S.n_app_total;
-                auto atm = [&](int r) { return ckm.at(r); };
-                if ((nat & 3) == 0) {
-                    save_rows<256>(save.v, V, L.sv, nat, ckm.n(), ftid, atm);
-                } else {
-                    for (int r = ftid >> 6; r < ckm.n(); r += 4)
-                        for (int c = ftid & 63; c < nat; c += 64) save.v[ckm.at(r) * nat + c] = V[r * L.sv + c];
-                }
-            }
             TF_MARK(0);
             lds_barrier();
             TF_MARK(1);
@@ -961,15 +937,56 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
             TF_MARK(4);
             lds_barrier();
             TF_MARK(5);
-            // ---- P4: units 6..8; the next chunk's info -> LDS
+            // ---- P4: units 6..8; the next chunk's info -> LDS; the basis fragments of P5 requested
             if (row_on && quads) gather_units<6, 3>(S, t, sub, vrow);
             if (on_n && sub == 0) put_info(info_next, smp, ckn.n(), nn_x, nn_v);
 #pragma unroll
             for (int a = 0; a < 3; ++a) nx_x[a] = nn_x[a];
+            f32x4 frb[2][KTB][1];
+            {
+                const int lane = tid & 63;
+                load_resident_frags<KTB>(S.basis, 16 * ktb, 0, ktb, lane, frb[0]);
+                load_resident_frags<KTB>(S.basis, 16 * ktb, 16 * (nb - 1), nb > 1 ? ktb : 0, lane, frb[1]);
+            }
             TF_MARK(6);
             lds_barrier();
             TF_MARK(7);
-            // ---- P5: (the MLP crew runs the output layer) the chunk after the next located, its descriptor published
+            // ---- P5: (the MLP crew runs the output layer) basis product of the chunk just gathered: feat = B V^T
+            // (tensoRF.py:263) and its view directions -> the side tile the MLP crew picks up in its next P1; this wave: sample
+            // tile fw, both feature tiles, two accumulator chains each.  Then the chunk after the next is located.
+            if (on_f && !TF_ABL(16)) {
+                const int lane = tid & 63, lc = lane & 15, lg = lane >> 4;
+                if (16 * fw < n16f) {
+                    const float* vp = V + (16 * fw + lc) * L.sv + 4 * lg;
+                    const float* iview_f = reinterpret_cast<const float*>(ldsb + (par ? L.offInfo1 : L.offInfo0)) + 3 * M;
+#pragma unroll
+                    for (int bf = 0; bf < 2; ++bf) {
+                        f32x4 bv[3];
+#pragma unroll
+                        for (int kg = 0; kg < 3; ++kg) bv[kg] = *reinterpret_cast<const f32x4*>(vp + 16 * kg);
+                        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kg = 0; kg < KTB; ++kg) {
+                            const f32x4 b = bv[kg % 3];
+                            if (kg + 3 < KTB) bv[kg % 3] = *reinterpret_cast<const f32x4*>(vp + 16 * (kg + 3));
+#pragma unroll
+                            for (int e = 0; e < 4; e += 2) {
+                                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(frb[bf][kg][0][e], b[e], acc0, 0, 0, 0);
+                                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(frb[bf][kg][0][e + 1], b[e + 1], acc1, 0, 0, 0);
+                            }
+                        }
+                        const f32x4 acc = acc0 + acc1;
+                        const int row = 16 * fw + lc;
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int f = 16 * bf + 4 * lg + e, d = f - S.app_dim;
+                            o[e] = d < 0 ? acc[e] : (d < 3 ? iview_f[row * 3 + d] : 0.f);
+                        }
+                        put3x4(H1p, M * 64, 64, row, 16 * bf + 4 * lg, o);
+                    }
+                }
+            }
             ckm = ckf;
             on_m = on_f;
             ckf = ckn;
@@ -1029,7 +1046,7 @@ int launch_shade(const TfShade* S, const TileSrc& src, float* rgb_out, float* fe
 int g_forward_variant = 0;
 
 bool pipe_fits(const TfShade& S) {
-    return S.head == TF_HEAD_MLP && S.feature_c == PIPE_FC && S.in_c <= PIPE_KX && S.app_dim <= 32 && S.n_app_total <= PIPE_KB;
+    return S.head == TF_HEAD_MLP && S.feature_c == PIPE_FC && S.in_c <= PIPE_KX && S.app_dim + 3 <= 32 && S.n_app_total <= PIPE_KB;
 }
 
 int launch_shade_pipe(const TfShade* S, const TileSrc& src, float* rgb_out, int blocks, hipStream_t st, const TfShadeSave& save) {
