@@ -616,32 +616,36 @@ __device__ __forceinline__ void save_rows3(float* dst, const char* base, int pla
         *reinterpret_cast<f32x4*>(dst + at(r) * (size_t)w + 4 * c4) = v;
     }
 }
-// acc[j] += W X^T for the wave's feature tile and sample tiles 0 .. NS-1 (NS = 2 or 4) over KS k-steps of 32: the six
-// products per (k-step, tile), smallest first, tiles of a pair alternating so that dependent MFMAs lie two apart
+// acc[j] += W X^T for the wave's feature tile and sample tiles 0 .. NS-1 (NS = 2 or 4) over KS k-steps of 32.  A step is
+// one (k-step, tile): its six products alternate between the tile's accumulator (lh, mh, hh) and a scratch accumulator (hl,
+// mm, hm — the small terms, added once at the end of the step), so that dependent MFMAs lie two apart.  The order is
+// pinned (sched_barrier): left to itself the compiler re-reads operand planes instead of keeping them and waits for every
+// read right behind its issue.
 template <int KS, int NS>
 __device__ __forceinline__ void mma3(const Frag3 (&a)[KS], const char* base, int plane, int row, f32x4 (&acc)[4], int lane) {
     const char* bp = base + (lane & 15) * row + 16 * (lane >> 4);
+    constexpr int N = KS * NS;
+    // (a step's planes are read at its start: the SIMD's other MLP wave covers the latency.  Reading them one step ahead
+    // costs 12 more registers than the kernel has — 24 spilled dwords reloaded inside this loop — and gains nothing: with
+    // 6 B per element read by all eight waves the two layers are bound by LDS bandwidth as much as by the matrix pipe,
+    // 864 KB per chunk = 6.8 k cycles at 128 B / cycle against 6.9 k cycles of MFMA issue)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+    for (int st = 0; st < N; ++st) {
+        const int ks = st / NS, j = st % NS;
+        const char* q = bp + (16 * j) * row + 64 * ks;
+        bf16x8 cur[3];
 #pragma unroll
-        for (int jp = 0; jp < NS / 2; ++jp) {
-            bf16x8 bh[2], bm[2], bl[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const char* q = bp + (16 * (2 * jp + t)) * row + 64 * ks;
-                bh[t] = *reinterpret_cast<const bf16x8*>(q);
-                bm[t] = *reinterpret_cast<const bf16x8*>(q + plane);
-                bl[t] = *reinterpret_cast<const bf16x8*>(q + 2 * plane);
-            }
-#pragma unroll
-            for (int term = 0; term < 6; ++term)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const bf16x8 av = term == 0 ? a[ks].l : (term == 1 ? a[ks].h : (term == 2 ? a[ks].m : (term == 3 ? a[ks].m : a[ks].h)));
-                    const bf16x8 bv = term == 0 ? bh[t] : (term == 1 ? bl[t] : (term == 2 ? bm[t] : (term == 3 ? bh[t] : (term == 4 ? bm[t] : bh[t]))));
-                    acc[2 * jp + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[2 * jp + t], 0, 0, 0);
-                }
-        }
+        for (int p = 0; p < 3; ++p) cur[p] = *reinterpret_cast<const bf16x8*>(q + p * plane);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks].h, cur[2], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks].l, cur[0], acc[j], 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks].m, cur[1], t, 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks].m, cur[0], acc[j], 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks].h, cur[1], t, 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks].h, cur[0], acc[j], 0, 0, 0);
+        acc[j] += t;
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S, const TileSrc src, float* __restrict__ rgb_out,

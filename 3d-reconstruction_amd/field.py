@@ -21,6 +21,7 @@ optimizers, `state_dict` and checkpoints interchange) but are stored channel-LAS
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -319,7 +320,7 @@ class TensorBase(nn.Module):
         # tf_shade_forward workgroups (of 512 CU slots) while the early sorts run next to it; the sort kernels need a CU
         # slot's LDS and registers (measured at config 2 with the 16-sample work split: 384 / 448 / 480 / 496 / 504 / 512 workgroups ->
         # 0.759 / 0.737 / 0.734 / 0.732 / 0.731 / 0.736 ms per step)
-        self.shade_wgs_beside_sort = 496
+        self.shade_wgs_beside_sort = int(os.environ.get("TF_SHADE_WGS_BESIDE_SORT", "496"))
         self.bin_tile, self.bin_bucket, self.bin_chunk = 8, 8, 512
         # entries per work item when the sorts run early — steps with few samples (EARLY_SORT_LIMITS), where 512-entry items
         # leave the scatter kernels short of workgroups: 0.731 -> 0.722 ms per captured step at config 2 (the large
