@@ -253,3 +253,72 @@ def test_sh_and_rgb_heads_alone_against_the_reference(recon):
     rgb = recon.TensorVMSplit(a, aabb, [8, 8, 8], S.LEGO_NEAR_FAR, dev)
     np.testing.assert_allclose(rgb.renderModule(pts, dirs, feats[:, :3].contiguous()).cpu().numpy(), z["rgb_passthrough"],
                                rtol=RTOL, atol=ATOL_RGB)
+
+
+@pytest.mark.parametrize("scene", ["lego_like", "ndc", "tiny_lists"])
+def test_pipelined_and_classic_forward_kernels_agree(recon, scene):
+    """tf_shade_forward has two kernels (csrc/shade.hip): the pipelined one-workgroup-per-CU kernel — hidden layers on
+    the bf16 pipe with three-piece operands — wherever its shape conditions hold, and the fp32 two-workgroups-per-CU
+    kernel elsewhere (tf_shade_forward_variant switches).  Same batch, same jitter, training mode (every row the
+    backward reads is written): sample colours, rendered colours and the saved V / X / H1 / H2 rows of both within
+    fp32 rounding of each other, and the SAME ReLU pattern — a unit may differ only where its activation is a tie
+    (|h| <= 1e-6 in the kernel that has it on; the reference's own GPU run moves such units too)."""
+    from recon_amd import _hip as H
+    from recon_amd import synthetic as S
+    dev = "cuda:0"
+    lib = H.lib()
+    torch.manual_seed(3)
+    ndc, white = False, True
+    if scene == "ndc":
+        aabb = torch.tensor(S.LLFF_AABB, device=dev)
+        model = recon.TensorVMSplit(S.lego_args(density_n_comp=(16, 4, 4), app_n_comp=(48, 12, 12)), aabb, [80, 88, 56], S.LLFF_NEAR_FAR, dev)
+        rays, ndc, white, N = S.llff_ndc_rays(3000).to(dev), True, False, 96
+        S.make_trained_like(model, recon.AlphaGridMask, mask_res=48, radius=0.9)
+    else:
+        aabb = torch.tensor(S.LEGO_AABB, device=dev)
+        model = recon.TensorVMSplit(S.lego_args(), aabb, [96, 96, 96], S.LEGO_NEAR_FAR, dev)
+        S.make_trained_like(model, recon.AlphaGridMask, mask_res=64, radius=0.8)
+        n_rays = 4096 if scene == "lego_like" else 150      # tiny_lists: a few samples per shard — chunks span several shards
+        allrays = S.blender_rays(1)
+        rays = allrays[torch.randperm(allrays.shape[0], generator=torch.Generator().manual_seed(5))[:n_rays]].to(dev).contiguous()
+        N = 333
+    jit = torch.rand(1 if ndc else rays.shape[0], N if ndc else 1, generator=torch.Generator().manual_seed(7))
+    out = {}
+    try:
+        for variant in (1, 0):
+            assert lib.tf_shade_forward_variant(variant) == 0
+            model._jitter_override = jit.clone()
+            model._bg_override = False
+            model.zero_grad(set_to_none=True)
+            rgb, _, nv = model(rays, None, white_bg=white, is_train=True, ndc_ray=ndc, N_samples=N)
+            torch.cuda.synchronize()
+            ws = model.last["ws"]
+            n_app = int(nv)
+            fc, kp = 128, (int(model.last["shade"].in_c) + 15) // 16 * 16
+            order = lambda t, w: packed_rows(ws, t, w)
+            out[variant] = dict(rgb_map=rgb.detach().cpu().numpy(), n=n_app,
+                                rgb=order(ws.rgb, 3), v=order(ws.dv, int(model.last["shade"].n_app_total)),
+                                x=order(ws.xs, kp), h1=order(ws.h1s, fc), h2=order(ws.h2s, fc))
+            del rgb
+    finally:
+        lib.tf_shade_forward_variant(0)
+        model._bg_override = None
+    a, b = out[1], out[0]          # classic, pipelined
+    assert a["n"] == b["n"] and a["n"] > (50 if scene == "tiny_lists" else 2000)
+    assert np.array_equal(a["v"], b["v"])                                    # the same gather arithmetic
+    np.testing.assert_allclose(b["x"], a["x"], rtol=0, atol=2e-6)            # basis product: other summation order
+    for k in ("h1", "h2"):
+        np.testing.assert_allclose(b[k], a[k], rtol=0, atol=2e-5 * max(1.0, float(np.abs(a[k]).max())))
+        flips = (a[k] > 0) != (b[k] > 0)
+        assert np.maximum(np.abs(a[k]), np.abs(b[k]))[flips].max(initial=0.0) <= 1e-6, (k, int(flips.sum()))
+    np.testing.assert_allclose(b["rgb"], a["rgb"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(b["rgb_map"], a["rgb_map"], rtol=0, atol=2e-6)
+    print({k: float(np.abs(a[k] - b[k]).max()) for k in ("x", "h1", "h2", "rgb", "rgb_map")},
+          {k: int(((a[k] > 0) != (b[k] > 0)).sum()) for k in ("h1", "h2")}, "units:", a["h1"].size)
+
+
+def packed_rows(ws, flat, width):
+    """rows (width floats each) of a packed per-sample buffer in ray-major order"""
+    off, cnt = ws.app_offset.cpu().numpy(), ws.app_count.cpu().numpy()
+    idx = np.concatenate([np.arange(o, o + k) for o, k in zip(off, cnt)]) if cnt.sum() else np.zeros(0, np.int64)
+    return flat.detach().view(-1, width).cpu().numpy()[idx]
