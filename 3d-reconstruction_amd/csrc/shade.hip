@@ -444,7 +444,7 @@ __host__ __device__ inline PipeLds pipe_lds() {
     return L;
 }
 
-#ifdef TF_PHASE_TIMING      // diagnostic build: 4 = no gather, 8 = no hidden-layer MFMAs, 16 = no basis / encodings (timing only)
+#ifdef TF_PHASE_TIMING      // diagnostic build: 4 = no gather, 8 = no hidden-layer MFMAs, 16 = no basis / encodings, 32 = no output layer (timing only)
 #define TF_ABL_INIT() const int abl_ = __builtin_amdgcn_readfirstlane(tf_dbg_flags)
 #define TF_ABL(bit) (abl_ & (bit))
 #define TF_PIPE_FLUSH(first_thread, arr) do { if ((int)threadIdx.x == (first_thread)) for (int _i = 0; _i < 16; ++_i) atomicAdd(&arr[_i], _ph[_i]); } while (0)
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
             TF_MARK(7);
             // ---- P5: output layer + sigmoid: o[c][s] = sum_f W3[c][f] H2[s][f], W3 as rows 0..2 of a 16-row operand tile
             // (its planes in LDS); wave w < 4 takes sample tile w.   mlp.py:36-38, 66-67
-            if (on && wave < nt) {
+            if (on && wave < nt && !TF_ABL(32)) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
                 const char* ap = w3p + min(lc, 2) * (FC * 2) + 16 * lg;
                 const char* bp = Xp + (16 * wave + lc) * HR + 16 * lg;
@@ -941,20 +941,27 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
             TF_MARK(4);
             lds_barrier();
             TF_MARK(5);
-            // ---- P4: units 6..8; the next chunk's info -> LDS; the basis fragments of P5 requested
+            // ---- P4: units 6..8; the next chunk's info -> LDS; the basis fragments of P5 fetched — and waited for HERE, where
+            // this crew has slack (their zero padding is a select per register that the scheduler otherwise sinks to the
+            // first MFMA of P5, behind a wait for the whole fetch)
+            f32x4 frb[2][KTB][1];
+            load_a_frags<1, KTB>(S.basis, 16 * ktb, 0, ktb, tid & 63, frb[0]);
             if (row_on && quads) gather_units<6, 3>(S, t, sub, vrow);
             if (on_n && sub == 0) put_info(info_next, smp, ckn.n(), nn_x, nn_v);
 #pragma unroll
             for (int a = 0; a < 3; ++a) nx_x[a] = nn_x[a];
-            f32x4 frb[2][KTB][1];
-            {
-                const int lane = tid & 63;
-                load_resident_frags<KTB>(S.basis, 16 * ktb, 0, ktb, lane, frb[0]);
-                load_resident_frags<KTB>(S.basis, 16 * ktb, 16 * (nb - 1), nb > 1 ? ktb : 0, lane, frb[1]);
+            load_a_frags<1, KTB>(S.basis, 16 * ktb, 16 * (nb - 1), ktb, tid & 63, frb[1]);
+#pragma unroll
+            for (int kg = 0; kg < KTB; ++kg) {
+                if (kg >= ktb) frb[0][kg][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (kg >= ktb || nb < 2) frb[1][kg][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
             TF_MARK(6);
             lds_barrier();
             TF_MARK(7);
+            TF_MARK(12);
             // ---- P5: (the MLP crew runs the output layer) basis product of the chunk just gathered: feat = B V^T
             // (tensoRF.py:263) and its view directions -> the side tile the MLP crew picks up in its next P1; this wave: sample
             // tile fw, both feature tiles, two accumulator chains each.  Then the chunk after the next is located.
@@ -980,17 +987,21 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
                             }
                         }
                         const f32x4 acc = acc0 + acc1;
+                        TF_MARK(14);
                         const int row = 16 * fw + lc;
                         f32x4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
+                        for (int e = 0; e < 4; ++e) {      // (branch-free: an unconditional read at a clamped index, two selects)
                             const int f = 16 * bf + 4 * lg + e, d = f - S.app_dim;
-                            o[e] = d < 0 ? acc[e] : (d < 3 ? iview_f[row * 3 + d] : 0.f);
+                            const float vw = iview_f[row * 3 + min(max(d, 0), 2)];
+                            o[e] = d < 0 ? acc[e] : (d < 3 ? vw : 0.f);
                         }
                         put3x4(H1p, M * 64, 64, row, 16 * bf + 4 * lg, o);
+                        TF_MARK(15);
                     }
                 }
             }
+            TF_MARK(11);
             ckm = ckf;
             on_m = on_f;
             ckf = ckn;
