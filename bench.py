@@ -532,7 +532,7 @@ def main():
                 "avg_launch_ms": ms / max(launches, 1e-9), "launches_per_step": launches, "ms_per_step": ms,
                 "note": "achieved = algorithmic bytes (flops) per launch / average launch duration (HIP events, eager pass); "
                         "traffic = (2 FETCH_SIZE + WRITE_SIZE) KB per launch from the committed PMC passes"}
-        key = {"tf_shade_backward": "shade_backward_kernel", "tf_shade_forward": "shade_forward_kernel",
+        key = {"tf_shade_backward": "shade_backward_kernel", "tf_shade_forward": "shade_forward_",
                "tf_march_forward": "march_forward_kernel", "tf_march_backward": "march_backward_kernel",
                "tf_adam_step": "adam_kernel"}.get(dom, "bin_scatter_kernel" if sc and mem == sc else dom)
         roof["traffic"] = pmc_traffic(key)

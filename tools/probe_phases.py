@@ -53,5 +53,4 @@ else:       # the pipelined kernel: work and barrier wait of each phase, per cre
     print("prologue, cycles per workgroup (8 batches x %d workgroups): MLP crew %.0f, gather crew %.0f" % (nwg, out[13]/8/nwg, out4[13]/8/nwg))
     print("gather crew, phase 5: basis product + side tile %.0f (operand reads + MFMAs %.0f, side-tile writes %.0f), then locate %.0f"
           % ((out4[11] + out4[14] + out4[15])/8/ntile, out4[14]/8/ntile, out4[15]/8/ntile, out4[8]/8/ntile))
-    print("inside phase 1 — MLP crew: loop top %.0f, basis reads + MFMAs %.0f (rest: epilogue, view);  gather crew: loop top %.0f, taps %.0f, unit 0 %.0f"
-          % (out[10]/8/ntile, out[11]/8/ntile, out4[10]/8/ntile, out4[11]/8/ntile, out4[12]/8/ntile))
+    print("loop top: MLP crew %.0f, gather crew %.0f" % (out[10]/8/ntile, out4[10]/8/ntile))
