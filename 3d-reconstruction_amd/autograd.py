@@ -174,6 +174,7 @@ class _RenderFn(torch.autograd.Function):
             # (the wait is on the forward only, the backward launches above are already queued).
             slot[1].synchronize()
             n_density, n_shaded, overflow, _ = slot[0].tolist()
+            model._last_sample_counts = (n_density, n_shaded)      # early_sort = 'auto' decides the next step from them
             ws = c['ws']
             if ws.right_sized:
                 if overflow:      # this batch did not fit its workspace: the gradients above are incomplete

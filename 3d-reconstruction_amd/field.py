@@ -312,7 +312,10 @@ class TensorBase(nn.Module):
         # True: sort the binned scatter's entries on a second stream right after the march kernel, next to the shading
         # kernel.  Pays when the sorts fit under the shading kernel (config 2: -8 % step time) and costs when they do not
         # (C4 / C5: 7x the entries, +15-20 %): GraphedTrainStep switches it on from the measured sizes of its warm-up step
-        self.early_sort = False
+        # 'auto' (default): eager steps decide from the previous step's sample counts, which the host has anyway
+        # (autograd: TfLive's pinned words) — EARLY_SORT_LIMITS; the drop-in eager step at config 2: 0.84 -> 0.71 ms
+        self.early_sort = {"0": False, "1": True}.get(os.environ.get("TF_EARLY_SORT", "auto"), 'auto')
+        self._last_sample_counts = None     # (density samples, shaded samples) of the last training step seen by the host
         self._sort_stream = None
         self._bin_status = None
         self._pack_external = None   # graph.GraphedTrainStep, while capturing: {'job': the forward's TfPackJob} instead of a launch
@@ -870,6 +873,41 @@ class TensorBase(nn.Module):
         finally:
             self._sampling_override = self._bg_override = None
 
+    EARLY_SORT_LIMITS = (500_000, 170_000)      # (density, shaded) samples per step up to which the sorts fit beside the shading kernel
+    EARLY_SORT_TRIAL = (8, 4, 1024)             # steps per block, blocks per trial (alternating off / on), steps between trials
+
+    def _early_sort_now(self):
+        """Whether this training forward issues the backward's counting sorts on the second stream (autograd._early_sort).
+        early_sort = 'auto' (eager steps): never for steps too large for the sorts to hide beside the shading kernel
+        (EARLY_SORT_LIMITS, from the previous step's counts); otherwise MEASURED — the second stream takes 0.05-0.1 ms off a
+        step whose host keeps up (0.71 -> 0.61 ms at config 2) and adds as much to a host-bound one (0.87 -> 0.96 ms on the
+        next box), and nothing the library can read says which it is.  So the first 32 steps run in blocks of 8 without /
+        with, the median step time (host clock, forward to forward, a block's first 3 steps dropped) picks the mode, and the
+        trial repeats every 1024 steps."""
+        if self.early_sort != 'auto':
+            return bool(self.early_sort)
+        c = self._last_sample_counts
+        if c is None or c[0] > self.EARLY_SORT_LIMITS[0] or c[1] > self.EARLY_SORT_LIMITS[1]:
+            return False
+        import time
+        st = self.__dict__.setdefault('_es_state', dict(t=None, mode=None, k=0, choice=None, dt={False: [], True: []}))
+        blk, nblk, period = self.EARLY_SORT_TRIAL
+        now = time.perf_counter()
+        k = st['k']
+        if st['t'] is not None and st['mode'] is not None and (k - 1) % period < blk * nblk and (k - 1) % blk >= 3:
+            st['dt'][st['mode']].append(now - st['t'])
+        st['t'], st['k'] = now, k + 1
+        if k % period == blk * nblk and st['dt'][False] and st['dt'][True]:       # the trial just ended: decide
+            med = {m: sorted(v)[len(v) // 2] for m, v in st['dt'].items()}
+            st['choice'] = med[True] < 0.98 * med[False]
+            st['dt'] = {False: [], True: []}
+        if k % period < blk * nblk:
+            mode = bool((k % period) // blk % 2)
+        else:
+            mode = bool(st['choice'])
+        st['mode'] = mode
+        return mode
+
     def workspace_bytes(self):
         """Bytes held by this model's training workspaces (tests / DESIGN's footprint figures)."""
         seen = {id(w): w for pool in self._train_ws.values() for w in pool}
@@ -950,7 +988,7 @@ class TensorBase(nn.Module):
             io.app_offset, io.app_count, io.val_count = ws.app_offset.data_ptr(), ws.app_count.data_ptr(), ws.val_count.data_ptr()
             io.counters = ws.counters.data_ptr()
             io.app_ray, io.app_xyz, io.app_w = ws.app_ray.data_ptr(), ws.app_xyz.data_ptr(), ws.app_w.data_ptr()
-            early = bool(save_valid and ws.binned_cfg is not None and self.early_sort and after_march is not None)
+            early = bool(save_valid and ws.binned_cfg is not None and self._early_sort_now() and after_march is not None)
             if save_valid:
                 io.val_idx, io.val_feat = ws.val_idx.data_ptr(), ws.val_feat.data_ptr()
                 if early:       # the forward places the density entries of the backward's binned scatter (TfMarchIO.ent_xyz)

@@ -453,8 +453,11 @@ class GraphedTrainStep:
                     n_app, n_den = (int(v) for v in ws.counters2d[:, :2].sum(0).tolist())
                     self._early = ws.binned_cfg is not None and n_den <= self.EARLY_SORT_LIMITS[0] \
                         and n_app <= self.EARLY_SORT_LIMITS[1]
-                if self._early and not self.model.early_sort:
-                    self.model.early_sort = True
+                # the captured step cannot decide per replay: the mode is fixed here (a model left on 'auto' would follow
+                # the host's last counts, which a replay does not update)
+                want = bool(self._early)
+                self.model.early_sort = want
+                if want != (self.model.last.get('sorted_on') is not None):
                     self._warm = max(self._warm, 1)               # one eager step in the new mode before the capture
                 self._early = None
             return self.loss

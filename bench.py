@@ -463,18 +463,27 @@ def main():
         early = model.early_sort
         if use_graph:
             opt, model.static_jitter = make_opt(False), None
-            model.early_sort = False        # the drop-in loop is the library's default: sorts inside the backward
+            # the drop-in loop runs the library's default ('auto'; TF_EARLY_SORT=0 / 1 pins it)
+            model.early_sort = {"0": False, "1": True}.get(os.environ.get("TF_EARLY_SORT", "auto"), 'auto')
+            model._last_sample_counts = None
         inst_step = train_step if args.mode == "train" else eval_step
         n_e = min(20, args.steps)
         for i in range(3):
             inst_step(i)
         if use_graph:
-            torch.cuda.synchronize()
-            te = time.perf_counter()
-            for i in range(n_e):
-                inst_step(args.warmup + i)
-            torch.cuda.synchronize()
-            eager_ms = (time.perf_counter() - te) / n_e * 1e3
+            # (the loop is host-paced — the renderer's float(num_valid) synchronises every step, renderer.py:24 — and a
+            # shared host makes 20-step timings scatter by 20 %: the median of five blocks is reported)
+            blocks = []
+            for b in range(5):
+                torch.cuda.synchronize()
+                te = time.perf_counter()
+                for i in range(n_e):
+                    inst_step((args.warmup + b * n_e + i) % n_steps)
+                torch.cuda.synchronize()
+                blocks.append((time.perf_counter() - te) / n_e * 1e3)
+            eager_ms = sorted(blocks)[2]
+            print(f"[bench] eager blocks {['%.3f' % b for b in blocks]} ms/step; sorts beside the forward: "
+                  f"{model.last.get('sorted_on') is not None} (early_sort = {model.early_sort!r})", file=sys.stderr)
             # per-kernel table: the captured step's own launches (its sorts run beside the shading kernel on a second
             # stream; here they are issued on ONE stream, so that every kernel is timed alone)
             model.early_sort, model._sort_inline = early, True

@@ -115,3 +115,32 @@ def test_free_mask_and_reso_helpers_match_reference(recon):
                 ref = z[f"{step}/{grp}/{k}"]
                 assert tuple(v.shape) == ref.shape, (step, grp, k)
                 assert np.array_equal(v.numpy(), ref), (step, grp, k)
+
+
+def test_early_sort_auto_rule_measures_and_picks_the_faster_mode():
+    """field.TensorBase._early_sort_now with early_sort = 'auto' (eager steps): alternating 8-step blocks without / with the
+    second-stream sorts, then the mode with the smaller median step time (host clock); never for steps beyond
+    EARLY_SORT_LIMITS; an explicit True / False is obeyed."""
+    import time
+    import types
+    from recon_amd import field as F
+    rule = F.TensorBase._early_sort_now
+
+    def run(cost_on, cost_off, counts=(1000, 1000), steps=48):
+        m = types.SimpleNamespace(early_sort='auto', _last_sample_counts=counts, EARLY_SORT_LIMITS=F.TensorBase.EARLY_SORT_LIMITS,
+                                  EARLY_SORT_TRIAL=F.TensorBase.EARLY_SORT_TRIAL)
+        out = []
+        for _ in range(steps):
+            on = rule(m)
+            out.append(on)
+            time.sleep(cost_on if on else cost_off)
+        return out
+    fast_on, fast_off = run(0.0004, 0.0012), run(0.0012, 0.0004)
+    assert fast_on[:32] == ([False] * 8 + [True] * 8) * 2 and fast_off[:32] == fast_on[:32]      # the trial
+    assert all(fast_on[33:]) and not any(fast_off[33:])                                            # the decision
+    assert not any(run(0.0, 0.0, counts=(10 ** 7, 1000), steps=40))                                # too many density samples
+    assert not any(run(0.0, 0.0, counts=None, steps=4))                                            # nothing known yet
+    m = types.SimpleNamespace(early_sort=True)
+    assert rule(m) is True
+    m.early_sort = False
+    assert rule(m) is False

@@ -399,6 +399,7 @@ def test_binned_scatter_refuses_positions_outside_its_buffers(recon):
     model = recon.TensorVMSplit(S.lego_args(density_n_comp=(8, 8, 8), app_n_comp=(16, 16, 16)), aabb, [32] * 3,
                                 S.LEGO_NEAR_FAR, dev)
     S.make_trained_like(model, recon.AlphaGridMask, mask_res=32, radius=0.7)
+    model.early_sort = False                           # the sorts run inside the backward, behind the poisoning below
     rays = S.blender_rays(1)[:2048].to(dev).contiguous()
     rgb, _, _ = model(rays, None, white_bg=True, is_train=True, N_samples=100)
     rgb.sum().backward()
