@@ -657,13 +657,18 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
     int* pre = reinterpret_cast<int*>(ldsb + L.offPre);
     char* w3p = ldsb + L.offW3;                      // planes [3][3][128] bf16
     float* biases = reinterpret_cast<float*>(ldsb + L.offBias);
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int g = 0; g < TF_N_SHARDS; ++g) {
-            pre[g] = run;
-            run += min(src.counters[g * TF_SHARD_STRIDE], src.seg_cap);
+    if (threadIdx.x < 64) {      // sample prefix over the 64 shards: one counter per lane, a wave scan
+        static_assert(TF_N_SHARDS == 64, "one shard per lane");
+        const int lane = threadIdx.x;
+        const int cnt = min(src.counters[lane * TF_SHARD_STRIDE], src.seg_cap);
+        int inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(inc, d);
+            if (lane >= d) inc += up;
         }
-        pre[TF_N_SHARDS] = run;
+        pre[lane] = inc - cnt;
+        if (lane == 63) pre[TF_N_SHARDS] = inc;
     }
     for (int i = threadIdx.x; i < 3 * FC; i += 768) put3(w3p, 3 * FC * 2, FC * 2, i / FC, i % FC, S.w3[i]);
     for (int i = threadIdx.x; i < 2 * FC + 3; i += 768) biases[i] = i < FC ? S.b1[i] : (i < 2 * FC ? S.b2[i - FC] : S.b3[i - 2 * FC]);
@@ -709,26 +714,17 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
             const int n = on ? ck.n() : 0, nt = (n + 15) >> 4, n16 = 16 * nt;
             const float* ixyz = reinterpret_cast<const float*>(ldsb + (par ? L.offInfo0 : L.offInfo1));
             const float* iview = ixyz + 3 * M;
-            auto at = [&](int r) { return ck.at(r); };
             TF_MARK(10);
             // ---- P1: the appearance features and view directions of this chunk — computed by the gather crew during the
-            // previous iteration's P5 into a side tile (planes of [64][32] in the idle H1 region) — move into the X planes;
-            // training: the V rows leave for the backward (the gather crew overwrites the tile from P2 on)
+            // previous iteration's P5 into a side tile (planes of [64][32] in the idle H1 region) — move into the X planes
             if (on && !TF_ABL(16)) {
                 for (int q = tid; q < 3 * n16 * 4; q += NC) {
                     const int pl = q / (n16 * 4), rc = q - pl * (n16 * 4);
                     *reinterpret_cast<u32x4*>(Xp + pl * XP + (rc >> 2) * XR + 16 * (rc & 3)) =
                         *reinterpret_cast<const u32x4*>(H1p + pl * (M * 64) + (rc >> 2) * 64 + 16 * (rc & 3));
                 }
-                if (save.v) {
-                    const int nat = S.n_app_total;
-                    if ((nat & 3) == 0) {
-                        save_rows<NC>(save.v, V, L.sv, nat, n, tid, at);
-                    } else {
-                        for (int r = wave; r < n; r += 8)
-                            for (int c = lane; c < nat; c += 64) save.v[ck.at(r) * nat + c] = V[r * L.sv + c];
-                    }
-                }
+                if (save.v && (S.n_app_total & 3) == 0)      // training: two thirds of the V rows (the gather crew: the rest)
+                    save_rows<768>(save.v, V, L.sv, S.n_app_total, n, tid, [&](int r) { return ck.at(r); });
             }
             TF_MARK(0);
             lds_barrier();
@@ -761,7 +757,6 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
             // ---- P3: H1 = relu(W1 X + b1)   (training rows leave behind the barrier that completes them, so that the
             // stores drain under the phase's arithmetic)
             if (on) {
-                if (save.x) save_rows3<NC>(save.x, Xp, XP, XR, kp1, n, tid, at);
                 f32x4 acc[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -917,9 +912,20 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
             make_vm_taps(S.grid, u, t);
             __builtin_amdgcn_sched_barrier(0);
             TF_MARK(11);
-            // ---- P1: (the MLP crew moves the feature tile and saves the V rows)
+            // ---- P1: (the MLP crew moves the feature tile) training: the V rows of the MLP crew's chunk leave for the
+            // backward, a third of them from here — this crew overwrites the tile from P2 on
             float nn_x[3], nn_v[3];
             int nn_ray;
+            auto atm = [&](int r) { return ckm.at(r); };
+            if (on_m && save.v) {
+                const int nat = S.n_app_total;
+                if ((nat & 3) == 0) {
+                    save_rows<768>(save.v, V, L.sv, nat, ckm.n(), tid, atm);      // (both crews: 768 threads)
+                } else {
+                    for (int r = ftid >> 6; r < ckm.n(); r += 4)
+                        for (int c = ftid & 63; c < nat; c += 64) save.v[ckm.at(r) * nat + c] = V[r * L.sv + c];
+                }
+            }
             TF_MARK(0);
             lds_barrier();
             TF_MARK(1);
@@ -932,8 +938,11 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
             TF_MARK(2);
             lds_barrier();
             TF_MARK(3);
-            // ---- P3: units 3..5 (other field shapes: the whole row, tap by tap); the next chunk's view directions requested
+            // ---- P3: units 3..5 (other field shapes: the whole row, tap by tap); the next chunk's view directions requested;
+            // training: the MLP crew's X rows (complete behind the barrier, overwritten by H2 in P4) leave from this crew's
+            // idle issue slots — reconstructing 10 row quads per thread costs the MLP crew 3 k cycles of its critical phase
             load_view(nn_ray, nn_v);
+            if (on_m && save.x) save_rows3<256>(save.x, Xp, XP, XR, kp1, ckm.n(), ftid, atm);
             if (row_on) {
                 if (quads) gather_units<3, 3>(S, t, sub, vrow);
                 else app_products(S, u, sub, vrow, 4);
