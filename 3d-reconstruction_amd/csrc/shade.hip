@@ -90,14 +90,7 @@ __global__ __launch_bounds__(512, 4) void shade_forward_kernel(const TfShade S, 
 
     int total = src.n_direct;
     if (src.counters) {   // sample prefix over shards (every workgroup computes the same table)
-        if (tid0 == 0) {
-            int run = 0;
-            for (int g = 0; g < TF_N_SHARDS; ++g) {
-                pre[g] = run;
-                run += min(src.counters[g * TF_SHARD_STRIDE], src.seg_cap);
-            }
-            pre[TF_N_SHARDS] = run;
-        }
+        shard_prefix(src.counters, src.seg_cap, pre, tid0);
         __syncthreads();
         total = pre[TF_N_SHARDS];
     }
@@ -657,19 +650,7 @@ __global__ __launch_bounds__(768) void shade_forward_pipe_kernel(const TfShade S
     int* pre = reinterpret_cast<int*>(ldsb + L.offPre);
     char* w3p = ldsb + L.offW3;                      // planes [3][3][128] bf16
     float* biases = reinterpret_cast<float*>(ldsb + L.offBias);
-    if (threadIdx.x < 64) {      // sample prefix over the 64 shards: one counter per lane, a wave scan
-        static_assert(TF_N_SHARDS == 64, "one shard per lane");
-        const int lane = threadIdx.x;
-        const int cnt = min(src.counters[lane * TF_SHARD_STRIDE], src.seg_cap);
-        int inc = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int up = __shfl_up(inc, d);
-            if (lane >= d) inc += up;
-        }
-        pre[lane] = inc - cnt;
-        if (lane == 63) pre[TF_N_SHARDS] = inc;
-    }
+    shard_prefix(src.counters, src.seg_cap, pre, threadIdx.x);
     for (int i = threadIdx.x; i < 3 * FC; i += 768) put3(w3p, 3 * FC * 2, FC * 2, i / FC, i % FC, S.w3[i]);
     for (int i = threadIdx.x; i < 2 * FC + 3; i += 768) biases[i] = i < FC ? S.b1[i] : (i < 2 * FC ? S.b2[i - FC] : S.b3[i - 2 * FC]);
     __syncthreads();

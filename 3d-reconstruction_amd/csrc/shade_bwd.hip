@@ -283,14 +283,7 @@ __global__ __launch_bounds__(512, 2) void shade_backward_kernel(const TfShade S,
     float tW3[3] = {0.f, 0.f, 0.f}, tb2 = 0.f;      // dW3 / db2 of thread (feature tid % FC, sample slice tid / FC)
     float ab1[4] = {0.f, 0.f, 0.f, 0.f};             // db1 of this lane's 4 features (accumulator layout), all chunks
 
-    if (tid0 == 0) {
-        int run = 0;
-        for (int g = 0; g < TF_N_SHARDS; ++g) {
-            pre[g] = run;
-            run += min(src.counters[g * TF_SHARD_STRIDE], src.seg_cap);
-        }
-        pre[TF_N_SHARDS] = run;
-    }
+    shard_prefix(src.counters, src.seg_cap, pre, tid0);
     for (int i = tid0; i < 3 * FCc; i += NT) cw3[i] = S.w3[i];
     for (int i = tid0; i < 5 * FCc; i += NT) sW3[i] = 0.f;
     __syncthreads();

@@ -482,6 +482,24 @@ struct TileSrc {          // where a tile's samples come from
     const float* feat_in;       // direct mode: (n, app_dim) appearance features given by the caller (renderModule alone)
 };
 
+// Exclusive prefix of the shards' (clamped) sample counts into pre[0 .. 64] by the first 64 threads of the workgroup: one
+// counter per lane and a wave scan (a single thread walking the 64 counters waits out their loads one after the other at
+// the start of every workgroup).  The caller synchronises.
+__device__ __forceinline__ void shard_prefix(const int* counters, int seg_cap, int* pre, int tid) {
+    static_assert(TF_N_SHARDS == 64, "one shard per lane");
+    if (tid < 64) {
+        const int cnt = min(counters[tid * TF_SHARD_STRIDE], seg_cap);
+        int inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(inc, d);
+            if (tid >= d) inc += up;
+        }
+        pre[tid] = inc - cnt;
+        if (tid == 63) pre[TF_N_SHARDS] = inc;
+    }
+}
+
 // Enumerates the tiles of all shards: returns false when t is past the last tile.
 __device__ __forceinline__ bool locate_tile(const TileSrc& src, const int* pre /*LDS prefix[65]*/, int t, int& s0,
                                             int& n) {
