@@ -1,13 +1,17 @@
-// shade.hip — appearance lookup + shading head on the packed app list.   gfx950, wave64, fp32 MFMA.
+// shade.hip — appearance lookup + shading head on the packed app list.   gfx950, wave64.
 //
-// A 512-thread workgroup (8 waves) shades one tile of TF_TILE = 64 samples, two workgroups per CU:
+// Two kernels behind tf_shade_forward (launch_shade / launch_shade_pipe pick by the head's shape):
+//   * shade_forward_pipe_kernel (further down): MLP heads with feature_c = 128 — one workgroup per CU, two crews of waves on
+//     consecutive chunks, hidden layers on the bf16 matrix pipe with three-piece operands (fp32 accuracy);
+//   * shade_forward_kernel (here): every other shape and the direct point-list entries.  A 512-thread workgroup (8 waves)
+//     shades one tile of TF_TILE = 64 samples, two workgroups per CU:
 //   1. gather: 8 lanes per sample read each bilinear tap of the channel-last appearance planes/lines as
 //      contiguous 16-B pieces (128 B per 8-lane group per tap) and write the plane*line products
 //      (sum n_comp wide) to an LDS tile V[64][.]                      tensoRF.py:238-260 / :394-410
 //   2. basis_mat: feat^T = B . V^T on v_mfma_f32_16x16x4_f32 (exact fp32)  tensoRF.py:263
 //   3. MLP input: [feat, view, PE blocks] built in LDS               mlp.py:8-13, 41-66
 //   4. 2 hidden layers on the fp32 MFMA (weights streamed from L2, activations in LDS), ReLU fused
-//      in the accumulator epilogue; output layer + sigmoid on the VALU   mlp.py:34-38, 66-67
+//      in the accumulator epilogue; output layer + sigmoid on the MFMA   mlp.py:34-38, 66-67
 // Workgroups are persistent and walk the tiles of the 64 packed-list shards.
 #include "tf_shade.h"
 

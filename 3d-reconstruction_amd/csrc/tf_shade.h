@@ -143,9 +143,10 @@ __device__ __forceinline__ void mma_frags(const f32x4 (&a)[KG][NF], const float*
 //     A1 = [wh, wh] per word:  sum wh (lo + hi)        A2 = [0, wl] per word:  sum wl hi
 // = wh xh + wh xl + wl xh: every product but lo.lo, error ~1e-5 of the result's largest entry (fp32 pipe: 3e-7;
 // profiles/r02_mfma_bf16_split_probe.txt), two MFMAs of 16 cycles per 16 k where the fp32 path issues four of 32: 4 x.
-// Only the BACKWARD's data-gradient products use it (dZ1 = W2^T dZ2, dX = W1^T dZ1): its ReLU masks come from the
-// forward's SAVED activations, so no unit can switch, and the gradient bar (2e-4 of a tensor's maximum) has room.  The
-// forward keeps fp32: a pre-activation moved by 1e-5 switches ReLU units against the reference.
+// Only the BACKWARD's products use it (dZ1 = W2^T dZ2, dX = W1^T dZ1 and the weight-gradient GEMMs): its ReLU masks come
+// from the forward's SAVED activations, so no unit can switch, and the gradient bar (2e-4 of a tensor's maximum) has room.
+// The FORWARD needs fp32 accuracy — a pre-activation moved by 1e-5 switches ReLU units against the reference — and gets it
+// on the same pipe from THREE pieces per operand (shade.hip: split3 / mma3).
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
